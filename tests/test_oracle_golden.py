@@ -1,0 +1,91 @@
+"""CPU: the C oracle (oracle/pinn_oracle.c) and the build-owned torch restatement
+(oracle/torch_ref.py) against golden vectors produced by the imported reference
+(oracle/gen_golden.py).  SURVEY.md 8(c) P4: fp64 agreement <= 1e-10."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_cases
+from oracle import torch_ref
+from oracle.pyoracle import Oracle
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_fp64_matches_reference(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    o = Oracle(str(g["eq"]), g["layers"].tolist(), g["lb"], g["ub"])
+    th = g["theta"].astype(np.float64)
+    n = len(g["x"])
+    der, f = o.forward(th, g["x"], g["t"])
+    for j in range(der.shape[2]):
+        assert rel(der[:, :, j], g["derivs64"][:, :, j]) < 1e-10, j
+    # residual: normalised by the largest term magnitude is overkill in fp64; plain rel-L2
+    assert rel(f, g["f64"]) < 1e-9
+    ls, grad = o.loss_grad(th, g["x"], g["t"], scale=1.0 / n)
+    assert abs(ls.sum() / n - g["loss_f64"]) <= 1e-10 * g["loss_f64"]
+    assert rel(grad, g["grad_f64"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_fp32_no_worse_than_reference_fp32(name):
+    """P1-P3 applied to the fp32 oracle (same bars the HIP path is held to)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    o = Oracle(str(g["eq"]), g["layers"].tolist(), g["lb"], g["ub"])
+    n = len(g["x"])
+    der, f = o.forward(g["theta"], g["x"], g["t"], dtype=np.float32)
+    K = o.K
+    for j in range(der.shape[2]):
+        order = j if j <= K else j - K - 1
+        tol = 1e-4 if order >= 7 else 3e-5
+        assert rel(der[:, :, j], g["derivs64"][:, :, j]) < tol, (j, rel(der[:, :, j], g["derivs64"][:, :, j]))
+    ref_err = np.linalg.norm(g["f32"].astype(np.float64) - g["f64"])
+    assert np.linalg.norm(f.astype(np.float64) - g["f64"]) <= max(4.0 * ref_err, 1e-5 * np.linalg.norm(g["f64"]))
+    ls, grad = o.loss_grad(g["theta"], g["x"], g["t"], scale=1.0 / n, dtype=np.float32)
+    ref_gerr = rel(g["grad_f32"], g["grad_f64"])
+    assert rel(grad, g["grad_f64"]) <= max(1e-5, 4.0 * ref_gerr)
+
+
+def test_oracle_vjp_mode_matches_loss_mode():
+    g = np.load(os.path.join(GOLDEN, "gnss_w50_xavier.npz"))
+    o = Oracle("gnss", g["layers"].tolist(), g["lb"], g["ub"])
+    th = g["theta"].astype(np.float64)
+    _, f = o.forward(th, g["x"], g["t"])
+    _, g1 = o.loss_grad(th, g["x"], g["t"], scale=0.25)
+    _, g2 = o.loss_grad(th, g["x"], g["t"], gbar=2 * 0.25 * f)
+    assert rel(g1, g2) < 1e-13
+
+
+@pytest.mark.parametrize("name", ["kdv7_3sol_xavier", "ch_ckpt", "gnss_w50_ckpt", "burgers_9x20_xavier", "kdv5_ckpt"])
+def test_torch_ref_matches_reference(name):
+    """The build-owned nested-autograd restatement reproduces the reference fp64 numbers."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eq = str(g["eq"])
+    net = torch_ref.make_dnn(g["layers"].tolist(), g["lb"], g["ub"], dtype=torch.float64)
+    torch_ref.load_flat_theta(net, g["theta"].astype(np.float64))
+    x = torch.tensor(g["x"].astype(np.float64))[:, None]
+    t = torch.tensor(g["t"].astype(np.float64))[:, None]
+    loss, grad, fs = torch_ref.loss_f_and_grad(eq, net, x, t)
+    f = np.concatenate([fi.numpy() for fi in fs], axis=1)
+    assert rel(f, g["f64"]) < 1e-9
+    assert abs(loss.item() - g["loss_f64"]) <= 1e-10 * g["loss_f64"]
+    assert rel(grad.numpy(), g["grad_f64"]) < 1e-9
+
+
+def test_known_answer_error_txt(golden_dir):
+    """error.txt:101-102: PI 73.pth + 73[-0.5,0.5]201*512.mat -> 3.743270e-01.
+    Plain-forward of the C oracle (EQ_NONE) over the full 201x512 grid."""
+    g = np.load(os.path.join(golden_dir, "predict_kdv7_73.npz"))
+    o = Oracle("none", g["layers"].tolist(), g["lb"], g["ub"])
+    X, T = np.meshgrid(g["x"], g["t"])
+    der, _ = o.forward(g["theta"], X.flatten(), T.flatten(), dtype=np.float32)
+    u_pred = der[:, 0, 0].astype(np.float64)
+    u_star = g["uu"].flatten()
+    err = np.linalg.norm(u_star - u_pred) / np.linalg.norm(u_star)
+    assert "%.6e" % err == "3.743270e-01"
+    assert abs(err - float(g["err_ref"])) < 1e-6
