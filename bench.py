@@ -1,0 +1,242 @@
+"""Benchmark of the PINN collocation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): collocation residual+grad evals/sec.  One "step" = one
+closure-equivalent of the PDE term: forward jets + residual + sum f^2 + gradient to
+the weights over the rank's shard of collocation points, plus (N>1) the
+all-reduce of [grad, sum f^2] that keeps L-BFGS consistent across ranks.
+Workload = BASELINE.json configs[2]: 7th-order KdV 3-soliton, net [2,50x4,1],
+1M synthetic collocation points PER GPU (weak scaling), weights
+xavier-normal(seed 1234), points uniform in [-15,15]x[-0.5,0.5].
+
+Besides the contract fields the JSON line carries
+  roofline      FP32 compute roofline of the dominant kernel (HIP-event timed)
+  cpu_baseline  the reference's method (nested torch.autograd.grad) timed on the
+                host cores on a bounded sample (rank 0, N=1 only)
+  train_steps_per_s   full backward()+Adam.step() iterations/s (IC/BC terms included)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic flops per point per closure, SURVEY 8(d): A = 3F
+FLOPS_PER_POINT = {"kdv7_3sol": 4.94e5, "kdv5": 3.68e5, "burgers": 1.96e5, "gnss": 9.5e5, "ch": 5.8e5}
+FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector == FP32-input MFMA
+
+WORKLOADS = {
+    "kdv7": dict(eq="kdv7_3sol", layers=[2, 50, 50, 50, 50, 1], lb=[-15.0, -0.5], ub=[15.0, 0.5],
+                 n=1_000_000, family="kdv7_3soliton", name="7kdv PI-7kdv3soliton, [2,50x4,1], N_f=1M per GPU"),
+    "kdv5": dict(eq="kdv5", layers=[2, 50, 50, 50, 50, 1], lb=[-10.0, -2.0], ub=[10.0, 2.0],
+                 n=100_000, family="kdv5_1soliton", name="5kdv PI-51, [2,50x4,1], N_f=100k"),
+    "gnss": dict(eq="gnss", layers=[2, 100, 100, 100, 100, 2], lb=[-5.0, -2.0], ub=[5.0, 0.0],
+                 n=2_000_000, family="gnss", name="NLS sw-GNSS-adamW, [2,100x4,2], N_f=2M"),
+    "ch": dict(eq="ch", layers=[2, 64, 64, 64, 64, 1], lb=[-15.0, -1.0], ub=[15.0, 1.0],
+               n=1_250_000, family="camassa_holm", name="CH PI, [2,64x4,1], N_f=1.25M per GPU (10M over 8)"),
+    "burgers": dict(eq="burgers", layers=[2] + [20] * 8 + [1], lb=[-1.0, 0.0], ub=[1.0, 0.99],
+                    n=10_000, family="burgers", name="Burgers, [2,20x8,1], N_f=10k"),
+}
+
+
+def cpu_baseline(w, budget_s=25.0):
+    """Reference method on the host: nested autograd (oracle/torch_ref.py), fp32."""
+    from oracle import torch_ref
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    net = torch_ref.make_dnn(w["layers"], w["lb"], w["ub"], seed=1234)
+    rng = np.random.default_rng(1234)
+    lb, ub = np.array(w["lb"]), np.array(w["ub"])
+    n = 20_000
+    X = torch.tensor((lb + (ub - lb) * rng.random((n, 2))).astype(np.float32))
+    x, t = X[:, 0:1].contiguous(), X[:, 1:2].contiguous()
+    torch_ref.loss_f_and_grad(w["eq"], net, x[:2000], t[:2000])  # warm-up
+    times = []
+    t_start = time.time()
+    while len(times) < 3 and (time.time() - t_start) < budget_s:
+        t0 = time.time()
+        torch_ref.loss_f_and_grad(w["eq"], net, x, t)
+        times.append(time.time() - t0)
+    per = float(np.median(times))
+    out = {"value": n / per, "unit": "collocation evals/s", "cores": cores, "kind": "port",
+           "sample": "%d closures of nested-autograd net_f+backward at N=%d (oracle/torch_ref.py, fp32, torch CPU)"
+                     % (len(times), n)}
+    # the C Taylor-jet oracle (same algorithm as the kernels) on the same cores, for context
+    try:
+        from oracle.pyoracle import Oracle
+        o = Oracle(w["eq"], w["layers"], w["lb"], w["ub"])
+        th = torch_ref.flat_theta(net).numpy()
+        Xn = X.numpy()
+        n2 = 100_000
+        X2 = (lb + (ub - lb) * rng.random((n2, 2))).astype(np.float32)
+        o.loss_grad(th, Xn[:1000, 0], Xn[:1000, 1], dtype=np.float32)
+        t0 = time.time()
+        o.loss_grad(th, X2[:, 0], X2[:, 1], scale=1.0 / n2, dtype=np.float32)
+        out["jet_c_port_value"] = n2 / (time.time() - t0)
+        out["jet_c_port_sample"] = "1 closure of the C Taylor-jet oracle (OpenMP, fp32) at N=%d" % n2
+    except Exception as ex:  # the oracle is optional for the bench
+        out["jet_c_port_value"] = None
+        out["jet_c_port_sample"] = "unavailable: %s" % ex
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kdv7", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override points per GPU")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        group = dist.group.WORLD
+
+    from pde_amd import scripts
+    from pde_amd import _native
+
+    w = dict(WORKLOADS[args.workload])
+    if args.n:
+        w["n"] = args.n
+    n_local = w["n"]
+    n_global = n_local * world
+    fam = getattr(scripts, w["family"])
+    cls = fam.PI.PhysicsInformedNN
+    cls = type("BenchPINN", (cls,), {"kernel": {"auto": 0, "valu": 1, "mfma": 2}[args.kernel]})
+    torch.manual_seed(1234)            # identical xavier weights on every rank
+    model = cls(w["layers"], np.array(w["lb"]), np.array(w["ub"]), process_group=group)
+    rng = np.random.default_rng(1234 + rank)
+    lb, ub = np.array(w["lb"]), np.array(w["ub"])
+    Xf = (lb + (ub - lb) * rng.random((n_local, 2))).astype(np.float32)
+    n0 = nb = 50
+    rs = np.random.default_rng(99)
+    x0 = lb[0] + (ub[0] - lb[0]) * rs.random((n0, 1))
+    tb = lb[1] + (ub[1] - lb[1]) * rs.random((nb, 1))
+    u0 = 2.0 / np.cosh(x0) ** 2
+    # every rank holds its own shard already: bypass the splitter
+    model.group = None
+    if w["eq"] == "gnss":
+        model.set_training_data(x0, u0, 0.1 * u0, tb, Xf)
+    elif w["eq"] == "burgers":
+        model.set_training_data(x0, -np.sin(np.pi * x0), tb, Xf, 0.01 / np.pi)
+    else:
+        model.set_training_data(x0, u0, tb, Xf)
+    model.group = group
+    model.n_f_global = n_global
+
+    def step():
+        for p in model.dnn.parameters():
+            p.grad = None
+        loss_f = model.loss_f()       # fused kernel pass (+ all-reduce when sharded)
+        loss_f.backward()             # hands the gradient to .grad (P-vector ops)
+        return loss_f
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_global * args.steps / elapsed
+
+    # ---- dominant kernel alone, HIP events on the launch stream (torch's current stream) ----
+    eng = model.engine_f
+    theta = model.dnn.flat_theta()
+    buf = torch.zeros(eng.P + eng.nf, device=dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kt = []
+    for _ in range(max(3, min(args.steps, 10))):
+        ev0.record()
+        eng.loss_grad(theta, model.xf, model.tf, 1.0 / n_global, buf[eng.P:], buf[:eng.P])
+        ev1.record()
+        ev1.synchronize()
+        kt.append(ev0.elapsed_time(ev1) * 1e-3)
+    k_avg = float(np.mean(kt))
+    flops = FLOPS_PER_POINT[w["eq"]] * n_local
+    achieved = flops / k_avg / 1e12
+
+    # ---- full training step (IC/BC terms + Adam) ----
+    train_sps = None
+    if args.train_steps > 0:
+        model.iter = 1
+        opt = torch.optim.Adam(model.dnn.parameters())
+        for _ in range(2):
+            opt.zero_grad(); model.backward(); opt.step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            opt.zero_grad(); model.backward(); opt.step()
+        sync()
+        train_sps = args.train_steps / (time.perf_counter() - t1)
+
+    if rank == 0:
+        line = {
+            "metric": "collocation residual+grad evals/sec",
+            "value": value,
+            "unit": "collocation evals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (uniform collocation points, xavier-normal weights seed 1234)",
+            "config": {"workload": w["name"], "equation": w["eq"], "layers": w["layers"],
+                       "points_per_gpu": n_local, "points_total": n_global,
+                       "parallelism": "dp%d over collocation points" % world,
+                       "kernel": {1: "valu", 2: "mfma"}[eng.kernel_kind]},
+            "train_steps_per_s": train_sps,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "kernel_ms": 1e3 * k_avg,
+                         "algorithmic_flops_per_point": FLOPS_PER_POINT[w["eq"]],
+                         "note": "FP32 compute roofline (vector == f32-input MFMA peak); "
+                                 "HBM traffic is 8 B/point algorithmic"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

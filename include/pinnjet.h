@@ -1,0 +1,132 @@
+/*
+ * pinnjet — C-ABI of the MI355X-native PINN collocation engine.
+ *
+ * The reference (Emily-Qu/PDE) has no FFI/operator interface: its de-facto
+ * boundary is the method surface of the per-script class PhysicsInformedNN
+ * (`self.dnn(X)`, `net_f`, `backward`, `predict`; 7kdv/PI-7kdv3soliton.py:76-184)
+ * and the torch.optim closure protocol.  This header is what a binding for that
+ * surface attaches to; each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch storages);
+ *    the library never frees or reallocates them;
+ *  - `theta` is one contiguous f32 buffer in state-dict order
+ *    [W0 (out,in) row-major, b0, W1, b1, ...]  (torch.nn.Linear layout,
+ *    7kdv/PI-7kdv3soliton.py:49-56; keys 1.layers.layer_i.{weight,bias});
+ *  - point coordinates are given as two base pointers plus one common element
+ *    stride: separate (N,1) columns -> stride 1 (xf/tf, :88-89); an (N,2)
+ *    row-major X_star -> x = X, t = X + 1, stride 2 (predict, :179-184);
+ *  - `*_accum` outputs are ACCUMULATED into (+=), matching `.grad` semantics
+ *    (callers zero first: optimizer.zero_grad(), :155,159);
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the
+ *    calls never synchronise the device;
+ *  - return value: 0 = ok, negative = error (pinn_error_string()); nothing is
+ *    printed and nothing aborts.
+ *  - a handle's entry points must not be called concurrently from two host
+ *    threads/streams (they share the handle's device workspace); distinct
+ *    handles are independent.
+ */
+#ifndef PINNJET_H
+#define PINNJET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PINN_MAX_LAYERS 16
+#define PINN_MAX_WIDTH 128
+#define PINN_MAX_OUT 2
+
+/* equation ids: which `net_f` body of the reference is evaluated */
+enum {
+    PINN_EQ_NONE = 0,    /* plain net_u (self.dnn), no derivatives                               */
+    PINN_EQ_BURGERS = 1, /* Burgers/Burgers_equation(PINN).py:126-131   coef[0]=nu               */
+    PINN_EQ_KDV5 = 2,    /* 5kdv/PI-51.py:132-140                       coef[0..3]=180,30,30,1   */
+    PINN_EQ_KDV7 = 3,    /* 7kdv/PI-7kdv3soliton.py:122-132 / PI-7kdv1soliton.py:132  coef[0..7] */
+    PINN_EQ_CH = 4,      /* CH/PI-CH-1soliton.py:131-138 (coef[0]=0), CH/bc-CH-1soliton.py:270-278 (coef[0]=2) */
+    PINN_EQ_GNSS = 5     /* NLS/sw-GNSS-adamW.py:159-180   coef[0..2]=a,b,c (c=0: plain NLS)     */
+};
+
+/* kernel selection */
+enum {
+    PINN_KERNEL_AUTO = 0,    /* MFMA path when the hidden width is >= 32, else the VALU path */
+    PINN_KERNEL_VALU = 1,    /* generic one-point-per-lane VALU kernels                      */
+    PINN_KERNEL_MFMA = 2     /* 16-point-tile FP32-MFMA kernels (uniform hidden width <= 128) */
+};
+
+typedef struct pinn_desc {
+    int32_t eq;                           /* PINN_EQ_*                                        */
+    int32_t n_lin;                        /* number of Linear layers = len(layers) - 1        */
+    int32_t widths[PINN_MAX_LAYERS + 1];  /* the script's `layers` list, widths[0] must be 2  */
+    float lb[2], ub[2];                   /* Scale bounds (x, t), float32 like the reference  */
+    float coef[8];                        /* residual coefficients, see the enum above        */
+    int32_t kernel;                       /* PINN_KERNEL_*                                    */
+    int32_t reserved[3];
+} pinn_desc;
+
+typedef struct pinn_handle pinn_handle;
+
+/* Create/destroy an engine for one (network shape, equation) on the CURRENT
+ * HIP device.  Owns only workspace.  Replaces the construction of
+ * Sequential(Scale, DNN) + the choice of net_f body (:77-81, :122-132). */
+int pinn_create(const pinn_desc *desc, pinn_handle **out);
+int pinn_destroy(pinn_handle *h);
+
+/* shape queries: P = parameter count, J = jet components per output carried by
+ * the residual kernels (K+1 x-orders then KT t-tangents), nf = residual
+ * components (2 for GNSS: (f_u, f_v)), nout = network outputs. */
+int pinn_param_count(const pinn_handle *h);
+int pinn_jet_count(const pinn_handle *h);
+int pinn_nf(const pinn_handle *h);
+int pinn_nout(const pinn_handle *h);
+/* which kernel family the handle resolved to (PINN_KERNEL_VALU / _MFMA) */
+int pinn_kernel_kind(const pinn_handle *h);
+
+/* net_u: out[n][nout] = dnn([x,t]).  Replaces `self.dnn(torch.concat([x,t],1))`
+ * (:99,102-103) and `predict` (:179-184). */
+int pinn_forward(pinn_handle *h, const float *theta, const float *x, const float *t,
+                 int64_t stride, int64_t n, float *out, void *stream);
+
+/* theta-gradient of sum_p sum_o gbar[p][o] * dnn(x_p,t_p)[o]; the backward of
+ * the data-loss terms loss0 / loss_b / loss1 / loss_prev (:99-105,
+ * 7kdv/sw-73.py:132-142, 7kdv/bc-7kdv3soliton.py:251-253). */
+int pinn_forward_vjp(pinn_handle *h, const float *theta, const float *x, const float *t,
+                     int64_t stride, int64_t n, const float *gbar, float *grad_theta_accum,
+                     void *stream);
+
+/* net_f: f_out[n][nf]; optional derivs_out[n][nout][J] = true derivatives
+ * (d^k u/dx^k, k=0..K, then d/dt of orders 0..KT-1).  Replaces net_f's nested
+ * torch.autograd.grad chain (:122-132).  Either output may be NULL. */
+int pinn_residual_fwd(pinn_handle *h, const float *theta, const float *x, const float *t,
+                      int64_t stride, int64_t n, float *f_out, float *derivs_out, void *stream);
+
+/* theta-gradient of sum_p sum_c gbar[p][c] * f_c(x_p,t_p): what autograd's
+ * backward through net_f's graph produces for an arbitrary loss on f. */
+int pinn_residual_vjp(pinn_handle *h, const float *theta, const float *x, const float *t,
+                      int64_t stride, int64_t n, const float *gbar, float *grad_theta_accum,
+                      void *stream);
+
+/* fused fast path of `backward()` for the collocation term (:107-108,111):
+ *   loss_sums_accum[c] += sum_p f_c^2            (unscaled, c < nf)
+ *   grad_theta_accum   += scale * d/dtheta sum_c sum_p f_c^2
+ * with scale = 1/N_global so that the result is the gradient of
+ * mean(square(f)) summed over components. */
+int pinn_loss_grad(pinn_handle *h, const float *theta, const float *x, const float *t,
+                   int64_t stride, int64_t n, float scale, float *loss_sums_accum,
+                   float *grad_theta_accum, void *stream);
+
+const char *pinn_error_string(int code);
+
+#define PINN_OK 0
+#define PINN_ERR_INVALID_DESC (-1)
+#define PINN_ERR_UNSUPPORTED (-2)
+#define PINN_ERR_HIP (-3)
+#define PINN_ERR_NULL (-4)
+#define PINN_ERR_ALLOC (-5)
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINNJET_H */

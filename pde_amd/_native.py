@@ -1,0 +1,185 @@
+"""ctypes binding of libpinnjet.so (include/pinnjet.h) and the Engine that
+PhysicsInformedNN drives.  There is no CPU fallback: if the HIP library is
+missing or no GPU is present, constructing a NativeEngine raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpinnjet.so")
+
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA = 0, 1, 2
+MAX_LAYERS = 16
+
+
+class PinnDesc(ctypes.Structure):
+    _fields_ = [
+        ("eq", ctypes.c_int32),
+        ("n_lin", ctypes.c_int32),
+        ("widths", ctypes.c_int32 * (MAX_LAYERS + 1)),
+        ("lb", ctypes.c_float * 2),
+        ("ub", ctypes.c_float * 2),
+        ("coef", ctypes.c_float * 8),
+        ("kernel", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 3),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/pinnjet.h declares
+SYMBOLS = [
+    "pinn_create", "pinn_destroy", "pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout",
+    "pinn_kernel_kind", "pinn_forward", "pinn_forward_vjp", "pinn_residual_fwd", "pinn_residual_vjp",
+    "pinn_loss_grad", "pinn_error_string",
+]
+
+
+def load_library():
+    """dlopen the in-tree HIP library; raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "pde_amd/libpinnjet.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float
+    lib.pinn_create.argtypes = [ctypes.POINTER(PinnDesc), ctypes.POINTER(vp)]
+    lib.pinn_destroy.argtypes = [vp]
+    for name in ("pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout", "pinn_kernel_kind"):
+        getattr(lib, name).argtypes = [vp]
+    lib.pinn_forward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp]
+    lib.pinn_forward_vjp.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
+    lib.pinn_residual_fwd.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
+    lib.pinn_residual_vjp.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
+    lib.pinn_loss_grad.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp, vp, vp]
+    lib.pinn_error_string.argtypes = [ctypes.c_int]
+    lib.pinn_error_string.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().pinn_error_string(rc).decode()
+        raise NativeError("%s failed: %s (%d)" % (what, msg, rc))
+
+
+def _split_xt(x, t):
+    """(x, t) -> (x_ptr_tensor, t_ptr_tensor, stride, n).  `t is None` means x is an
+    (N,2) row-major [x,t] array (predict's X_star, 7kdv/PI-7kdv3soliton.py:179-184)."""
+    if t is None:
+        X = x
+        assert X.dim() == 2 and X.shape[1] == 2
+        X = X.contiguous()
+        return X, X, X.data_ptr(), X.data_ptr() + 4, 2, X.shape[0]
+    x = x.reshape(-1).contiguous()
+    t = t.reshape(-1).contiguous()
+    assert x.numel() == t.numel()
+    return x, t, x.data_ptr(), t.data_ptr(), 1, x.numel()
+
+
+class NativeEngine:
+    """One (network shape, equation) on one GPU.  All tensors are float32 CUDA
+    tensors on `device`; kernels run on torch's current stream."""
+
+    def __init__(self, equation, layers, lb, ub, device, kernel=KERNEL_AUTO):
+        if not torch.cuda.is_available():
+            raise NativeError("pde_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.device(device)
+        assert self.device.type == "cuda"
+        self.equation = equation
+        d = PinnDesc()
+        d.eq = equation.eq_id
+        d.n_lin = len(layers) - 1
+        if d.n_lin > MAX_LAYERS:
+            raise NativeError("too many layers")
+        for i, w in enumerate(layers):
+            d.widths[i] = int(w)
+        for i in range(2):
+            d.lb[i] = float(lb[i])
+            d.ub[i] = float(ub[i])
+        for i, c in enumerate(equation.coef):
+            d.coef[i] = float(c)
+        d.kernel = kernel
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_create(ctypes.byref(d), ctypes.byref(self._h)), "pinn_create")
+        self.P = self.lib.pinn_param_count(self._h)
+        self.J = self.lib.pinn_jet_count(self._h)
+        self.nf = self.lib.pinn_nf(self._h)
+        self.nout = self.lib.pinn_nout(self._h)
+        self.kernel_kind = self.lib.pinn_kernel_kind(self._h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self.lib.pinn_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk_theta(self, theta):
+        assert theta.dtype == torch.float32 and theta.is_contiguous() and theta.numel() == self.P
+        assert theta.device == self.device
+
+    # ---- net_u ----
+    def forward(self, theta, x, t=None):
+        self._chk_theta(theta)
+        kx, kt, px, pt, stride, n = _split_xt(x, t)
+        out = torch.empty((n, self.nout), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_forward(self._h, theta.data_ptr(), px, pt, stride, n, out.data_ptr(),
+                                         self._stream()), "pinn_forward")
+        return out
+
+    def forward_vjp(self, theta, x, t, gbar, grad_accum):
+        self._chk_theta(theta)
+        kx, kt, px, pt, stride, n = _split_xt(x, t)
+        gbar = gbar.reshape(n, self.nout).contiguous().float()
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_forward_vjp(self._h, theta.data_ptr(), px, pt, stride, n, gbar.data_ptr(),
+                                             grad_accum.data_ptr(), self._stream()), "pinn_forward_vjp")
+
+    # ---- net_f ----
+    def residual_fwd(self, theta, x, t, want_derivs=False):
+        self._chk_theta(theta)
+        kx, kt, px, pt, stride, n = _split_xt(x, t)
+        f = torch.empty((n, self.nf), dtype=torch.float32, device=self.device)
+        der = torch.empty((n, self.nout, self.J), dtype=torch.float32, device=self.device) if want_derivs else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_residual_fwd(self._h, theta.data_ptr(), px, pt, stride, n, f.data_ptr(),
+                                              der.data_ptr() if want_derivs else None, self._stream()),
+                   "pinn_residual_fwd")
+        return (f, der) if want_derivs else f
+
+    def residual_vjp(self, theta, x, t, gbar, grad_accum):
+        self._chk_theta(theta)
+        kx, kt, px, pt, stride, n = _split_xt(x, t)
+        gbar = gbar.reshape(n, self.nf).contiguous().float()
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_residual_vjp(self._h, theta.data_ptr(), px, pt, stride, n, gbar.data_ptr(),
+                                              grad_accum.data_ptr(), self._stream()), "pinn_residual_vjp")
+
+    def loss_grad(self, theta, x, t, scale, loss_sums_accum, grad_accum):
+        """loss_sums_accum[nf] += sum f_c^2 ; grad_accum[P] += scale * d/dtheta sum f^2."""
+        self._chk_theta(theta)
+        kx, kt, px, pt, stride, n = _split_xt(x, t)
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_loss_grad(self._h, theta.data_ptr(), px, pt, stride, n, float(scale),
+                                           loss_sums_accum.data_ptr(), grad_accum.data_ptr(), self._stream()),
+                   "pinn_loss_grad")

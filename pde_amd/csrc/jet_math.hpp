@@ -1,0 +1,264 @@
+// Per-lane Taylor-jet arithmetic shared by the VALU and MFMA kernels.
+//
+// A "jet" of a scalar g(x,t) at one collocation point is the vector
+//   [ c_0 .. c_K | d_0 .. d_{KT-1} ],   c_k = (d^k g/dx^k)/k!,  d_k = (d^k (dg/dt)/dx^k)/k!
+// i.e. normalised Taylor coefficients in x plus the x-Taylor coefficients of
+// the t-derivative.  J = K+1+KT components.  Linear layers act on each
+// component separately; tanh acts through the recurrences below.  This
+// replaces the reference's nested torch.autograd.grad chain
+// (7kdv/PI-7kdv3soliton.py:122-132) by one forward sweep per point.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pinn {
+
+enum { EQ_NONE = 0, EQ_BURGERS = 1, EQ_KDV5 = 2, EQ_KDV7 = 3, EQ_CH = 4, EQ_GNSS = 5 };
+
+template <int EQ> struct EqTraits;
+template <> struct EqTraits<EQ_NONE>    { static constexpr int K = 0, KT = 0; };
+template <> struct EqTraits<EQ_BURGERS> { static constexpr int K = 2, KT = 1; };
+template <> struct EqTraits<EQ_KDV5>    { static constexpr int K = 5, KT = 1; };
+template <> struct EqTraits<EQ_KDV7>    { static constexpr int K = 7, KT = 1; };
+template <> struct EqTraits<EQ_CH>      { static constexpr int K = 3, KT = 3; };
+template <> struct EqTraits<EQ_GNSS>    { static constexpr int K = 3, KT = 1; };
+
+constexpr int MAXOUT = 2;
+
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    // tanh(x) = sign(x) * (1 - e) / (1 + e), e = exp(-2|x|).  |abs err| < 2e-7:
+    // v_exp_f32 and v_rcp_f32 are ~1 ulp; for |x| < 0.04 switch to the odd
+    // series to keep the relative error small where 1-e cancels.
+    const float ax = fabsf(x);
+    const float e = __expf(-2.0f * ax);
+    float r = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float x2 = x * x;
+    const float s = ax * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.05396825f * x2)));
+    r = ax < 0.04f ? s : r;
+    return copysignf(r, x);
+}
+
+// ---- tanh on a jet -----------------------------------------------------------
+// y' = (1-y^2) z'  =>  k y_k = sum_{j=1..k} j z_j w_{k-j},  w = 1 - y*y.
+// z, y: [J] (x orders then t tangents);  w: [K+1].
+template <int K, int KT>
+__device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float (&y)[K + 1 + KT],
+                                             float (&w)[K + 1])
+{
+    y[0] = tanhf(z[0]);
+    w[0] = fmaf(-y[0], y[0], 1.0f);
+#pragma unroll
+    for (int k = 1; k <= K; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 1; j <= k; ++j) s = fmaf((float)j * z[j], w[k - j], s);
+        y[k] = s * (1.0f / (float)k);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i <= k; ++i) q = fmaf(y[i], y[k - i], q);
+        w[k] = -q;
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j <= k; ++j) s = fmaf(w[j], z[K + 1 + k - j], s);
+        y[K + 1 + k] = s;
+    }
+}
+
+// w jets from y alone (used by the reverse sweep, which re-reads y instead of w)
+template <int K>
+__device__ __forceinline__ void w_from_y(const float *y, float (&w)[K + 1])
+{
+    w[0] = fmaf(-y[0], y[0], 1.0f);
+#pragma unroll
+    for (int k = 1; k <= K; ++k) {
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i <= k; ++i) q = fmaf(y[i], y[k - i], q);
+        w[k] = -q;
+    }
+}
+
+// reverse of tanh_jet_fwd: yb (adjoint of y, modified in place) -> zb.
+template <int K, int KT>
+__device__ __forceinline__ void tanh_jet_bwd(const float (&z)[K + 1 + KT], const float (&y)[K + 1 + KT],
+                                             const float (&w)[K + 1], float (&yb)[K + 1 + KT],
+                                             float (&zb)[K + 1 + KT])
+{
+    float wb[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) { wb[k] = 0.0f; zb[k] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) zb[K + 1 + k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+#pragma unroll
+        for (int j = 0; j <= k; ++j) {
+            wb[j] = fmaf(yb[K + 1 + k], z[K + 1 + k - j], wb[j]);
+            zb[K + 1 + k - j] = fmaf(yb[K + 1 + k], w[j], zb[K + 1 + k - j]);
+        }
+    }
+#pragma unroll
+    for (int k = K; k >= 1; --k) {
+        const float m2 = -2.0f * wb[k];
+#pragma unroll
+        for (int m = 0; m <= k; ++m) yb[m] = fmaf(m2, y[k - m], yb[m]);
+        const float g = yb[k] * (1.0f / (float)k);
+#pragma unroll
+        for (int j = 1; j <= k; ++j) {
+            const float gj = g * (float)j;
+            zb[j] = fmaf(gj, w[k - j], zb[j]);
+            wb[k - j] = fmaf(gj, z[j], wb[k - j]);
+        }
+    }
+    yb[0] = fmaf(-2.0f * wb[0], y[0], yb[0]);
+    zb[0] = yb[0] * w[0];
+}
+
+__host__ __device__ constexpr float factorial(int k)
+{
+    float f = 1.0f;
+    for (int i = 2; i <= k; ++i) f *= (float)i;
+    return f;
+}
+
+// ---- residuals ---------------------------------------------------------------
+// D[o][k] = d^k u_o/dx^k, T[o][k] = d/dt d^k u_o/dx^k (true derivatives).
+// eval() writes f[0..NF-1]; adj() accumulates fb[c]*df_c/d(.) into Db/Tb.
+template <int EQ> struct Residual;
+
+template <> struct Residual<EQ_NONE> {  // plain net_u: f_o = u_o  (self.dnn(X), :99)
+    static constexpr int K = 0, KT = 0;
+    template <class A> __device__ static void eval(const A &D, const A &, const float *, int nout, float *f)
+    {
+        f[0] = D[0][0];
+        if (nout > 1) f[1] = D[1][0];
+    }
+    template <class A> __device__ static void adj(const A &, const A &, const float *, int nout,
+                                                  const float *fb, A &Db, A &)
+    {
+        Db[0][0] += fb[0];
+        if (nout > 1) Db[1][0] += fb[1];
+    }
+};
+
+template <> struct Residual<EQ_BURGERS> {  // Burgers/Burgers_equation(PINN).py:126-131
+    static constexpr int K = 2, KT = 1;
+    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    {
+        const float *u = D[0];
+        f[0] = T[0][0] + u[0] * u[1] - c[0] * u[2];
+    }
+    template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
+                                                  const float *fb, A &Db, A &Tb)
+    {
+        const float *u = D[0];
+        const float g = fb[0];
+        Tb[0][0] += g;
+        Db[0][0] += g * u[1];
+        Db[0][1] += g * u[0];
+        Db[0][2] += g * (-c[0]);
+    }
+};
+
+template <> struct Residual<EQ_KDV5> {  // 5kdv/PI-51.py:132-140
+    static constexpr int K = 5, KT = 1;
+    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    {
+        const float *u = D[0];
+        f[0] = T[0][0] + c[0] * u[0] * u[0] * u[1] + c[1] * u[1] * u[2] + c[2] * u[0] * u[3] + c[3] * u[5];
+    }
+    template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
+                                                  const float *fb, A &Db, A &Tb)
+    {
+        const float *u = D[0];
+        const float g = fb[0];
+        Tb[0][0] += g;
+        Db[0][0] += g * (2.0f * c[0] * u[0] * u[1] + c[2] * u[3]);
+        Db[0][1] += g * (c[0] * u[0] * u[0] + c[1] * u[2]);
+        Db[0][2] += g * (c[1] * u[1]);
+        Db[0][3] += g * (c[2] * u[0]);
+        Db[0][5] += g * c[3];
+    }
+};
+
+template <> struct Residual<EQ_KDV7> {  // 7kdv/PI-7kdv3soliton.py:132, 7kdv/PI-7kdv1soliton.py:132
+    static constexpr int K = 7, KT = 1;
+    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    {
+        const float *u = D[0];
+        f[0] = T[0][0] + c[0] * u[0] * u[0] * u[0] * u[1] + c[1] * u[1] * u[1] * u[1]
+             + c[2] * u[0] * u[1] * u[2] + c[3] * u[0] * u[0] * u[3] + c[4] * u[2] * u[3]
+             + c[5] * u[1] * u[4] + c[6] * u[0] * u[5] + c[7] * u[7];
+    }
+    template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
+                                                  const float *fb, A &Db, A &Tb)
+    {
+        const float *u = D[0];
+        const float g = fb[0];
+        Tb[0][0] += g;
+        Db[0][0] += g * (3.0f * c[0] * u[0] * u[0] * u[1] + c[2] * u[1] * u[2] + 2.0f * c[3] * u[0] * u[3] + c[6] * u[5]);
+        Db[0][1] += g * (c[0] * u[0] * u[0] * u[0] + 3.0f * c[1] * u[1] * u[1] + c[2] * u[0] * u[2] + c[5] * u[4]);
+        Db[0][2] += g * (c[2] * u[0] * u[1] + c[4] * u[3]);
+        Db[0][3] += g * (c[3] * u[0] * u[0] + c[4] * u[2]);
+        Db[0][4] += g * (c[5] * u[1]);
+        Db[0][5] += g * (c[6] * u[0]);
+        Db[0][7] += g * c[7];
+    }
+};
+
+template <> struct Residual<EQ_CH> {  // CH/PI-CH-1soliton.py:131-138; CH/bc-CH-1soliton.py:270-278 (c[0]=2)
+    static constexpr int K = 3, KT = 3;
+    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    {
+        const float *u = D[0];
+        f[0] = T[0][0] - T[0][2] + 3.0f * u[0] * u[1] - 2.0f * u[2] * u[1] + c[0] * u[1] - u[3] * u[0];
+    }
+    template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
+                                                  const float *fb, A &Db, A &Tb)
+    {
+        const float *u = D[0];
+        const float g = fb[0];
+        Tb[0][0] += g;
+        Tb[0][2] -= g;
+        Db[0][0] += g * (3.0f * u[1] - u[3]);
+        Db[0][1] += g * (3.0f * u[0] - 2.0f * u[2] + c[0]);
+        Db[0][2] += g * (-2.0f * u[1]);
+        Db[0][3] += g * (-u[0]);
+    }
+};
+
+template <> struct Residual<EQ_GNSS> {  // NLS/sw-GNSS-adamW.py:159-180 (c[2]=0: NLS/sw-PINN-rogue.py:179-180)
+    static constexpr int K = 3, KT = 1;
+    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    {
+        const float *u = D[0], *v = D[1];
+        const float rho = u[0] * u[0] + v[0] * v[0];
+        f[0] = T[0][0] + c[0] * v[2] + c[1] * rho * v[0] - c[2] * (u[3] + 6.0f * rho * u[1]);
+        f[1] = T[1][0] - c[0] * u[2] - c[1] * rho * u[0] - c[2] * (v[3] + 6.0f * rho * v[1]);
+    }
+    template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
+                                                  const float *fb, A &Db, A &Tb)
+    {
+        const float *u = D[0], *v = D[1];
+        const float a = c[0], b = c[1], cc = c[2];
+        const float rho = u[0] * u[0] + v[0] * v[0];
+        const float g0 = fb[0], g1 = fb[1];
+        Tb[0][0] += g0;
+        Tb[1][0] += g1;
+        Db[0][0] += g0 * (2.0f * b * u[0] * v[0] - 12.0f * cc * u[0] * u[1])
+                  + g1 * (-b * (rho + 2.0f * u[0] * u[0]) - 12.0f * cc * u[0] * v[1]);
+        Db[1][0] += g0 * (b * (rho + 2.0f * v[0] * v[0]) - 12.0f * cc * v[0] * u[1])
+                  + g1 * (-2.0f * b * v[0] * u[0] - 12.0f * cc * v[0] * v[1]);
+        Db[0][1] += g0 * (-6.0f * cc * rho);
+        Db[1][1] += g1 * (-6.0f * cc * rho);
+        Db[1][2] += g0 * a;
+        Db[0][2] -= g1 * a;
+        Db[0][3] -= g0 * cc;
+        Db[1][3] -= g1 * cc;
+    }
+};
+
+}  // namespace pinn

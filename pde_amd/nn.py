@@ -1,0 +1,173 @@
+"""`self.dnn` of the reference, backed by the native engine.
+
+The reference builds `torch.nn.Sequential(Scale(lb, ub), DNN(layers))`
+(7kdv/PI-7kdv3soliton.py:80) whose state-dict keys are
+`1.layers.layer_{i}.{weight,bias}`.  NetU keeps exactly that module tree (so
+shipped .pth checkpoints load and saved ones load back into the reference) but
+
+  * every Linear weight/bias is a view into ONE flat float32 buffer `theta`
+    in state-dict order, which is what the kernels read;
+  * calling the module runs the fused Scale+MLP HIP kernel through a
+    torch.autograd.Function instead of a chain of addmm/tanh ATen ops.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+class Scale(torch.nn.Module):
+    """Same role and attribute names as the reference's Scale (:34-41); the affine
+    map itself is fused into the kernels, `forward` is kept for completeness."""
+
+    def __init__(self, lb, ub, device):
+        super().__init__()
+        self.lb = torch.tensor(np.asarray(lb, dtype=np.float64)).float().to(device)
+        self.ub = torch.tensor(np.asarray(ub, dtype=np.float64)).float().to(device)
+
+    def forward(self, X):
+        return 2.0 * (X - self.lb) / (self.ub - self.lb) - 1.0
+
+
+class DNN(torch.nn.Module):
+    """Module tree of the reference's DNN (:43-61): layers.layer_i / activation_i."""
+
+    def __init__(self, layers):
+        super().__init__()
+        self.depth = len(layers) - 1
+        mods = []
+        for i in range(self.depth - 1):
+            mods.append(("layer_%d" % i, torch.nn.Linear(layers[i], layers[i + 1])))
+            mods.append(("activation_%d" % i, torch.nn.Tanh()))
+        mods.append(("layer_%d" % (self.depth - 1), torch.nn.Linear(layers[-2], layers[-1])))
+        self.layers = torch.nn.Sequential(OrderedDict(mods))
+
+    def linears(self):
+        return [m for m in self.layers if isinstance(m, torch.nn.Linear)]
+
+
+def xavier(m):
+    """reference :70-74"""
+    if isinstance(m, torch.nn.Linear):
+        torch.nn.init.xavier_normal_(m.weight)
+        if m.bias is not None:
+            torch.nn.init.zeros_(m.bias)
+
+
+def _split_flat(flat, params):
+    out, off = [], 0
+    for p in params:
+        n = p.numel()
+        out.append(flat[off:off + n].view(p.shape))
+        off += n
+    return out
+
+
+class _NetUFn(torch.autograd.Function):
+    """u = dnn([x,t]) with a theta-gradient.  No gradient flows to the inputs: the
+    reference differentiates w.r.t. x,t only inside net_f, which has its own op."""
+
+    @staticmethod
+    def forward(ctx, net, X, *params):
+        theta = net.flat_theta()
+        ctx.net = net
+        ctx.X = X
+        return net.engine.forward(theta, X, None)
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        theta = net.flat_theta()
+        g = torch.zeros_like(theta)
+        net.engine.forward_vjp(theta, ctx.X, None, gout, g)
+        return (None, None) + tuple(_split_flat(g, net.param_list))
+
+
+class _ResidualFn(torch.autograd.Function):
+    """f = net_f(x, t) as an (N, nf) tensor whose backward reaches the weights."""
+
+    @staticmethod
+    def forward(ctx, net, engine, x, t, *params):
+        theta = net.flat_theta()
+        ctx.net, ctx.engine, ctx.x, ctx.t = net, engine, x, t
+        return engine.residual_fwd(theta, x, t)
+
+    @staticmethod
+    def backward(ctx, gout):
+        net = ctx.net
+        theta = net.flat_theta()
+        g = torch.zeros_like(theta)
+        ctx.engine.residual_vjp(theta, ctx.x, ctx.t, gout, g)
+        return (None, None, None, None) + tuple(_split_flat(g, net.param_list))
+
+
+class _ResidualLossFn(torch.autograd.Function):
+    """loss_f = sum_c mean_p f_c^2 in ONE fused kernel pass that also produces
+    d loss_f / d theta (the reference's loss_f + its share of loss.backward(),
+    :107-108,111).  With a process group the local partial sums of the shard are
+    all-reduced once: [grad (P floats), sum f_c^2 (nf floats)]."""
+
+    @staticmethod
+    def forward(ctx, net, engine, x, t, n_global, group, *params):
+        theta = net.flat_theta()
+        buf = torch.zeros(engine.P + engine.nf, dtype=torch.float32, device=theta.device)
+        if x.numel() > 0:
+            engine.loss_grad(theta, x, t, 1.0 / float(n_global), buf[engine.P:], buf[:engine.P])
+        if group is not None:
+            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
+        ctx.net = net
+        ctx.grad_flat = buf[:engine.P]
+        return buf[engine.P:].sum() / float(n_global)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.grad_flat * gout
+        return (None, None, None, None, None, None) + tuple(_split_flat(g, ctx.net.param_list))
+
+
+class NetU(torch.nn.Sequential):
+    """Sequential(Scale, DNN) with a flat parameter buffer and a native forward."""
+
+    def __init__(self, layers, lb, ub, device, engine_factory):
+        device = torch.device(device)
+        super().__init__(Scale(lb, ub, device), DNN(layers))
+        self.layer_sizes = list(layers)
+        self._device = device
+        self[1].apply(xavier)
+        self._flatten_params()
+        # engine for plain forward / data-loss terms (equation "none")
+        self.engine = engine_factory(None)
+
+    # -- flat parameter buffer -------------------------------------------------
+    def _flatten_params(self):
+        params = []
+        for lin in self[1].linears():
+            params += [lin.weight, lin.bias]
+        flat = torch.cat([p.detach().reshape(-1).float() for p in params]).to(self._device).contiguous()
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self._theta = flat
+        self.param_list = params
+
+    def flat_theta(self):
+        """The contiguous float32 parameter vector the kernels read.  Parameters are
+        views into it; if something re-pointed them (e.g. `.to()`), re-flatten."""
+        off = 0
+        base = self._theta.data_ptr()
+        for p in self.param_list:
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                self._flatten_params()
+                break
+            off += p.numel()
+        return self._theta
+
+    def forward(self, X):
+        X = X.to(self._device, torch.float32)
+        if X.dim() != 2 or X.shape[1] != 2:
+            raise ValueError("dnn expects an (N,2) tensor of [x,t] rows")
+        if X.shape[0] == 0:
+            return torch.zeros((0, self.layer_sizes[-1]), device=self._device)
+        return _NetUFn.apply(self, X.detach().contiguous(), *self.param_list)

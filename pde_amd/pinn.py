@@ -1,0 +1,356 @@
+"""Drop-in `PhysicsInformedNN` / `bcPhysicsInformedNN` for the Emily-Qu/PDE scripts.
+
+Same constructor, `set_training_data`, `net_u`/`dnn`, `net_f`, `backward`,
+`train`, `predict`, `save_model`, `load_model` and log-line formats as the
+per-script classes of the reference (canonical copy:
+7kdv/PI-7kdv3soliton.py:76-184; sliding-window variant 7kdv/sw-73.py:76-230;
+bc variant 7kdv/bc-7kdv3soliton.py:198-329; two-output GNSS variant
+NLS/sw-GNSS-adamW.py:76-233; Burgers Burgers/Burgers_equation(PINN).py:82-183),
+but `net_f`, the loss reduction and the weight gradient run in the HIP kernels
+of libpinnjet.so instead of nested torch.autograd.grad graphs.
+
+What differs per script in the reference (residual formula, IC time `t0`,
+boundary-loss form, log format, AdamW vs Adam, L-BFGS settings) is a
+`Variant`; `pde_amd.scripts` instantiates one class per reference script.
+"""
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import equations
+from ._native import KERNEL_AUTO, NativeEngine
+from .nn import NetU, _ResidualFn, _ResidualLossFn
+
+
+class FileWriter:
+    """reference :63-68 — append one line, re-opening the file each time."""
+
+    def __init__(self, logfilename, base_dir):
+        self.file_path = os.path.join(base_dir, "log", logfilename)
+
+    def write(self, content, mode="a"):
+        os.makedirs(os.path.dirname(self.file_path), exist_ok=True)
+        with open(self.file_path, mode, encoding="utf-8") as f:
+            f.write(content + "\n")
+
+
+@dataclass
+class Variant:
+    equation: str = "kdv7_3sol"
+    t0: float = -0.5                 # IC time literal
+    bc: str = "periodic"             # "periodic" (:105) or "dirichlet" (Burgers :109)
+    style: str = "pi"                # "pi" | "sw" | "bc"  (set_training_data signature, extra loss term)
+    optimizer: str = "adam"          # "adam" | "adamw"
+    weight_decay: float = 1e-2       # AdamW (7kdv/sw73-adamW.py:170)
+    lbfgs: dict = field(default_factory=lambda: dict(
+        lr=1.0, max_eval=5000, history_size=50, tolerance_grad=1e-5))
+
+
+def _as_col(a):
+    a = np.asarray(a, dtype=np.float64)
+    return a.reshape(-1, 1) if a.ndim < 2 else a
+
+
+class PhysicsInformedNN:
+    variant = Variant()
+    base_dir = os.getcwd()           # where model/ and log/ live (<script dir> in the reference)
+    default_device = None            # None -> current CUDA device
+    kernel = KERNEL_AUTO
+    engine_factory = None            # test hook: callable(equation|None, layers, lb, ub, device) -> engine
+
+    def __init__(self, layers, lb, ub, prev_model=None, process_group=None):
+        v = self.variant
+        dev = self.default_device
+        if dev is None:
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        self.device = torch.device(dev) if dev is not None else None
+        self.layers = list(layers)
+        self._lb64 = np.asarray(lb, dtype=np.float64).reshape(-1)
+        self._ub64 = np.asarray(ub, dtype=np.float64).reshape(-1)
+        lb32 = self._lb64.astype(np.float32)
+        ub32 = self._ub64.astype(np.float32)
+        self.equation = equations.get(v.equation)
+        if self.equation.nout != layers[-1]:
+            raise ValueError("equation %s needs %d network outputs" % (v.equation, self.equation.nout))
+
+        def factory(eq):
+            e = eq if eq is not None else equations.get("none")
+            if type(self).engine_factory is not None:
+                return type(self).engine_factory(e, self.layers, lb32, ub32, self.device)
+            if self.device is None:
+                raise RuntimeError("pde_amd needs an AMD GPU; there is no CPU fallback")
+            return NativeEngine(e, self.layers, lb32, ub32, self.device, kernel=self.kernel)
+
+        if self.device is None and type(self).engine_factory is None:
+            raise RuntimeError("pde_amd needs an AMD GPU; there is no CPU fallback")
+        dd = self.device if self.device is not None else torch.device("cpu")
+        self.device = dd
+        self.lb = torch.tensor(self._lb64).float().to(dd)
+        self.ub = torch.tensor(self._ub64).float().to(dd)
+        self.dnn = NetU(self.layers, lb32, ub32, dd, factory)
+        self.engine_f = factory(self.equation)
+        if prev_model is not None:   # sliding-window warm start, 7kdv/sw-73.py:83-85
+            self.dnn.load_state_dict(prev_model.dnn.state_dict())
+            print("Loaded weights from previous model")
+        self.group = process_group
+        self.iter = 0
+        self.logfilename = None
+        self.X_prev = None
+        self.nu = None
+
+    # ------------------------------------------------------------------ data
+    def _t(self, a):
+        return torch.tensor(_as_col(a)).float().to(self.device)
+
+    def _shard(self, Xf):
+        """Contiguous equal shards of the collocation points over the ranks of the
+        process group; remainder goes to the low ranks."""
+        Xf = np.asarray(Xf)
+        self.n_f_global = Xf.shape[0]
+        if self.group is None:
+            return Xf
+        import torch.distributed as dist
+        R, r = dist.get_world_size(self.group), dist.get_rank(self.group)
+        q, rem = divmod(Xf.shape[0], R)
+        lo = r * q + min(r, rem)
+        hi = lo + q + (1 if r < rem else 0)
+        return Xf[lo:hi]
+
+    def set_training_data(self, x0, u0, *args, **kw):
+        """Signatures of the reference, by variant:
+          pi      (x0, u0, tb, Xf)                       7kdv/PI-7kdv3soliton.py:83
+          burgers (x0, u0, tb, Xf, nu)                   Burgers/Burgers_equation(PINN).py:89
+          sw      (x0, u0, tb, Xf, X_prev=None, u_prev=None)              7kdv/sw-73.py:89
+          gnss    (x0, u0, v0, tb, Xf[, X_prev, u_prev, v_prev])          NLS/sw-GNSS-adamW.py:89
+          bc      (x0, u0, t0, u1, tb, Xf, Xh)           7kdv/bc-7kdv3soliton.py:205
+        numpy float64 arrays in, float32 device tensors kept."""
+        v = self.variant
+        two = self.equation.nout == 2
+        args = list(args)
+        self.x0 = self._t(x0)
+        self.u0 = self._t(u0)
+        t0 = v.t0
+        self.u1 = self.x1 = self.t1 = None
+        if v.style == "bc":
+            names = ["t0", "u1", "tb", "Xf", "Xh"] if not two else ["v0", "t0", "u1", "v1", "tb", "Xf", "Xh"]
+            vals = dict(zip(names, args))
+            vals.update(kw)
+            t0 = float(vals["t0"])
+            if two:
+                self.v0 = self._t(vals["v0"])
+                self.v1 = self._t(vals["v1"])
+            self.u1 = self._t(vals["u1"])
+            Xh = np.asarray(vals["Xh"], dtype=np.float64)
+            self.x1, self.t1 = self._t(Xh[:, 0:1]), self._t(Xh[:, 1:2])
+            tb, Xf = vals["tb"], vals["Xf"]
+        else:
+            names = (["v0"] if two else []) + ["tb", "Xf"]
+            if self.equation.name == "burgers":
+                names += ["nu"]
+            names += ["X_prev", "u_prev"] + (["v_prev"] if two else [])
+            vals = dict(zip(names, args))
+            vals.update(kw)
+            if two:
+                self.v0 = self._t(vals["v0"])
+            tb, Xf = vals["tb"], vals["Xf"]
+            if vals.get("nu") is not None:
+                self.set_nu(vals["nu"])
+            if vals.get("X_prev") is not None:
+                self.X_prev = torch.tensor(np.asarray(vals["X_prev"], dtype=np.float64)).float().to(self.device)
+                self.u_prev = self._t(vals["u_prev"])
+                if two:
+                    self.v_prev = self._t(vals["v_prev"])
+            else:
+                self.X_prev = None
+        self.tb = self._t(tb)
+        Xf = self._shard(np.asarray(Xf, dtype=np.float64))
+        self.xf = torch.tensor(Xf[:, 0:1]).float().to(self.device).contiguous()
+        self.tf = torch.tensor(Xf[:, 1:2]).float().to(self.device).contiguous()
+        # the reference reads module globals lb/ub here (:92-93); the sw variants use self.lb
+        self.x_lb = torch.full_like(self.tb, float(self.lb[0]))
+        self.x_ub = torch.full_like(self.tb, float(self.ub[0]))
+        self.t0 = torch.full_like(self.x0, t0)
+
+    def set_nu(self, nu):
+        """Burgers viscosity: a float32 tensor in the reference (:96); a new value needs
+        a new engine because the coefficient is baked into the descriptor."""
+        nu32 = float(np.float32(nu))
+        self.nu = torch.tensor(nu32).float().to(self.device)
+        if abs(nu32 - self.equation.coef[0]) > 0:
+            self.equation = equations.get(self.equation.name, [nu32])
+            lb32, ub32 = self._lb64.astype(np.float32), self._ub64.astype(np.float32)
+            if type(self).engine_factory is not None:
+                self.engine_f = type(self).engine_factory(self.equation, self.layers, lb32, ub32, self.device)
+            else:
+                self.engine_f = NativeEngine(self.equation, self.layers, lb32, ub32, self.device, kernel=self.kernel)
+
+    # ------------------------------------------------------------------ model
+    def net_u(self, x, t):
+        return self.dnn(torch.cat([x, t], dim=1))
+
+    def net_f(self, x, t):
+        """Residual at (x,t): (N,1) tensor ((f_u, f_v) tuple for GNSS), differentiable
+        w.r.t. the weights.  Reference: nested autograd chain, :122-132."""
+        x = x.detach().to(self.device, torch.float32)
+        t = t.detach().to(self.device, torch.float32)
+        f = _ResidualFn.apply(self.dnn, self.engine_f, x, t, *self.dnn.param_list)
+        if self.equation.nf == 2:
+            return f[:, 0:1], f[:, 1:2]
+        return f
+
+    def loss_f(self):
+        """mean(square(f)) (summed over components) over ALL ranks' collocation points,
+        fused with its weight gradient; one all-reduce when sharded."""
+        return _ResidualLossFn.apply(self.dnn, self.engine_f, self.xf, self.tf, self.n_f_global, self.group,
+                                     *self.dnn.param_list)
+
+    def _mse(self, pred, *targets):
+        s = 0
+        for c, tgt in enumerate(targets):
+            s = s + torch.mean(torch.square(pred[:, c:c + 1] - tgt))
+        return s
+
+    def backward(self):
+        """Same loss composition as the reference's backward() (:97-120 and variants);
+        returns the 0-dim loss with `.grad` accumulated on dnn.parameters()."""
+        v = self.variant
+        two = self.equation.nout == 2
+        out0 = self.dnn(torch.cat([self.x0, self.t0], dim=1))
+        loss0 = self._mse(out0, self.u0, self.v0) if two else self._mse(out0, self.u0)
+
+        out_lb = self.dnn(torch.cat([self.x_lb, self.tb], dim=1))
+        out_ub = self.dnn(torch.cat([self.x_ub, self.tb], dim=1))
+        if v.bc == "dirichlet":
+            loss_b = torch.mean(torch.square(out_lb)) + torch.mean(torch.square(out_ub))
+        else:
+            loss_b = sum(torch.mean(torch.square(out_lb[:, c:c + 1] - out_ub[:, c:c + 1]))
+                         for c in range(self.equation.nout))
+
+        loss_f = self.loss_f()
+
+        loss1 = None
+        loss_prev = 0
+        if v.style == "bc" and self.u1 is not None:
+            out1 = self.dnn(torch.cat([self.x1, self.t1], dim=1))
+            loss1 = self._mse(out1, self.u1, self.v1) if two else self._mse(out1, self.u1)
+        if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
+            outp = self.dnn(self.X_prev)
+            loss_prev = self._mse(outp, self.u_prev, self.v_prev) if two else self._mse(outp, self.u_prev)
+            if self.iter % 100 == 0:
+                print(f"Overlap loss: {loss_prev.item():.5e}")
+
+        loss = loss0 + loss_b + loss_f
+        if loss1 is not None:
+            loss = loss + loss1
+        loss = loss + loss_prev
+        loss.backward()
+
+        if self.iter % 100 == 0:
+            if v.style == "sw":
+                message = 'Iter: %d, Loss: %.5e, Loss0: %.5e, Loss_b: %.5e, Loss_f: %.5e, Loss_prev: %.5e' % (
+                    self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item(), float(loss_prev))
+            elif loss1 is not None:
+                message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_1: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
+                    self.iter, loss.item(), loss0.item(), loss1.item(), loss_b.item(), loss_f.item())
+            else:
+                message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
+                    self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item())
+            if self.logfilename is not None:
+                self.writer.write(message)
+            if self._is_rank0():
+                print(message)
+        self.iter += 1
+        return loss
+
+    def _is_rank0(self):
+        if self.group is None:
+            return True
+        import torch.distributed as dist
+        return dist.get_rank(self.group) == 0
+
+    # ------------------------------------------------------------------ train
+    def train(self, nIter, logfilename=None, init_iter=0, LBFGS_max_iter=50000):
+        """Adam/AdamW for nIter steps, then one L-BFGS(strong_wolfe) step — :135-165.
+        The optimizers are torch.optim (third-party in the reference too)."""
+        v = self.variant
+        self.dnn.train()
+        self.iter = init_iter
+        params = list(self.dnn.parameters())
+        if v.optimizer == "adamw":
+            self.optimizer_Adam = torch.optim.AdamW(params, weight_decay=v.weight_decay)
+        else:
+            self.optimizer_Adam = torch.optim.Adam(params)
+        self.optimizer_LBFGS = torch.optim.LBFGS(
+            params, lr=v.lbfgs.get("lr", 1.0), max_iter=LBFGS_max_iter,
+            max_eval=v.lbfgs.get("max_eval", 5000), history_size=v.lbfgs.get("history_size", 50),
+            tolerance_grad=v.lbfgs.get("tolerance_grad", 1e-5),
+            tolerance_change=1.0 * np.finfo(float).eps, line_search_fn="strong_wolfe")
+        self.logfilename = logfilename if self._is_rank0() else None
+        if self.logfilename is not None:
+            self.writer = FileWriter(logfilename, self.base_dir)
+            self.writer.write("Start Training:", mode='w')
+        start_time = time.time()
+        for _ in range(nIter):
+            self.optimizer_Adam.zero_grad()
+            self.backward()
+            self.optimizer_Adam.step()
+
+        def LBFGS_callback():
+            self.optimizer_LBFGS.zero_grad()
+            return self.backward()
+        if LBFGS_max_iter > 0:
+            self.optimizer_LBFGS.step(LBFGS_callback)
+        elapsed = time.time() - start_time
+        if self.logfilename is not None:
+            self.writer.write('Training time: %.4f' % (elapsed))
+        if self._is_rank0():
+            print('Training time: %.4f' % (elapsed))
+
+    # ------------------------------------------------------------------ io
+    def load_model(self, filename):
+        if filename is not None:
+            load_path = os.path.join(self.base_dir, 'model', filename)
+            sd = torch.load(load_path, map_location=self.device, weights_only=True)
+            self.dnn.load_state_dict(sd)
+            print(f"Model parameters loaded from {load_path}.")
+
+    def save_model(self, filename):
+        if filename is not None:
+            save_path = os.path.join(self.base_dir, 'model', filename)
+            os.makedirs(os.path.dirname(save_path), exist_ok=True)
+            sd = OrderedDictClone(self.dnn.state_dict())
+            torch.save(sd, save_path)
+            print(f"Model parameters saved to {save_path}.")
+
+    def predict(self, X_star):
+        """u on X_star (M,2) as numpy (M,1); (u, v) tuple for two-output nets — :179-184."""
+        X = torch.tensor(np.asarray(X_star, dtype=np.float64)).float().to(self.device)
+        self.dnn.eval()
+        with torch.no_grad():
+            out = self.dnn(X)
+        out = out.detach().cpu().numpy()
+        if self.equation.nout == 2:
+            return out[:, 0:1], out[:, 1:2]
+        return out
+
+
+def OrderedDictClone(sd):
+    from collections import OrderedDict
+    return OrderedDict((k, v.detach().clone()) for k, v in sd.items())
+
+
+class bcPhysicsInformedNN(PhysicsInformedNN):
+    """Segments 1..3 of the bc-PINN drivers: extra loss1 over all earlier grid points
+    (7kdv/bc-7kdv3soliton.py:198-262, CH/bc-CH-1soliton.py:204-262)."""
+    variant = Variant(style="bc")
+
+
+def make_class(name, base=PhysicsInformedNN, **variant_kw):
+    """Build a per-script class: `make_class("PI73", equation="kdv7_3sol", t0=-0.5)`."""
+    style = variant_kw.get("style", base.variant.style)
+    v = Variant(**{**dict(style=style), **variant_kw})
+    return type(name, (base,), {"variant": v})

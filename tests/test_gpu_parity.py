@@ -1,0 +1,257 @@
+"""GPU: parity of the HIP path against the oracle / golden vectors, through the
+C-ABI (pde_amd._native is a ctypes binding of include/pinnjet.h).
+
+Tolerances (north_star + SURVEY 8(c)), all relative L2 against the reference's
+fp64 result stored in tests/golden:
+  P1  every derivative: <= 1e-5 for x-order <= 6, <= 1e-4 for order 7 (or 3x the
+      reference's own fp32 error on that derivative where that is larger)
+  P2  residual: ||f - f64|| <= 1e-5 * ||largest residual term||, and no worse than
+      4x the reference's own fp32 error
+  P3  loss / flat gradient: <= max(1e-5, 4x the reference's own fp32 error) (loss: also
+      2x the reference's fp32 relative error of f, since loss = ||f||^2/n);
+      at xavier weights (no cancellation) the reference fp32 error is ~2e-7 so
+      the bar is 1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_cases
+from oracle.pyoracle import Oracle
+from pde_amd import equations, scripts
+from pde_amd._native import KERNEL_MFMA, KERNEL_VALU, NativeEngine, NativeError
+
+pytestmark = pytest.mark.gpu
+
+KINDS = [("valu", KERNEL_VALU), ("mfma", KERNEL_MFMA)]
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def engine_for(g, kernel, eq=None):
+    e = equations.get(str(g["eq"]) if eq is None else eq)
+    try:
+        return NativeEngine(e, g["layers"].tolist(), g["lb"].astype(np.float32), g["ub"].astype(np.float32),
+                            dev(), kernel=kernel)
+    except NativeError as ex:
+        if "unsupported" in str(ex):
+            pytest.skip("kernel family does not cover this shape: %s" % ex)
+        raise
+
+
+def cu(a):
+    return torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev())
+
+
+def term_scale(g):
+    """RMS-ish magnitude of the largest term of the residual (for P2)."""
+    d = g["derivs64"]
+    return max(np.linalg.norm(d[:, :, j]) for j in range(d.shape[2]))
+
+
+@pytest.mark.parametrize("kname,kernel", KINDS)
+@pytest.mark.parametrize("name", golden_cases())
+def test_residual_and_derivatives(name, kname, kernel):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eng = engine_for(g, kernel)
+    theta, x, t = cu(g["theta"]), cu(g["x"]), cu(g["t"])
+    f, der = eng.residual_fwd(theta, x, t, want_derivs=True)
+    torch.cuda.synchronize()
+    der, f = der.cpu().numpy(), f.cpu().numpy()
+    K = eng.equation.K
+    for j in range(der.shape[2]):
+        order = j if j <= K else j - K - 1
+        tol = 1e-4 if order >= 7 else 1e-5
+        # a few trained nets (CH peakon) make the reference's OWN fp32 derivatives worse than 1e-5;
+        # there the bar is "no worse than 3x the reference's fp32 error"
+        tol = max(tol, 3.0 * rel(g["derivs32"][:, :, j], g["derivs64"][:, :, j]))
+        assert rel(der[:, :, j], g["derivs64"][:, :, j]) < tol, (j, rel(der[:, :, j], g["derivs64"][:, :, j]))
+    err = np.linalg.norm(f.astype(np.float64) - g["f64"])
+    ref_err = np.linalg.norm(g["f32"].astype(np.float64) - g["f64"])
+    # P2: the residual is a sum of products of derivatives; scale by the largest derivative norm
+    assert err <= 1e-5 * max(term_scale(g), np.linalg.norm(g["f64"]))
+    assert err <= max(4.0 * ref_err, 1e-5 * np.linalg.norm(g["f64"]))
+
+
+@pytest.mark.parametrize("kname,kernel", KINDS)
+@pytest.mark.parametrize("name", golden_cases())
+def test_loss_and_gradient(name, kname, kernel):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eng = engine_for(g, kernel)
+    theta, x, t = cu(g["theta"]), cu(g["x"]), cu(g["t"])
+    n = len(g["x"])
+    ls = torch.zeros(eng.nf, device=dev())
+    grad = torch.zeros(eng.P, device=dev())
+    eng.loss_grad(theta, x, t, 1.0 / n, ls, grad)
+    torch.cuda.synchronize()
+    loss = ls.sum().item() / n
+    ref_lerr = abs(float(g["loss_f32"]) - float(g["loss_f64"])) / float(g["loss_f64"])
+    ref_gerr = rel(g["grad_f32"], g["grad_f64"])
+    # loss = ||f||^2/n, so its relative error is bounded by twice the relative error of f; the
+    # reference's own fp32 f error is the noise floor at trained (cancelling) weights
+    ref_ferr = rel(g["f32"], g["f64"])
+    assert abs(loss - g["loss_f64"]) / g["loss_f64"] <= max(1e-5, 4 * ref_lerr, 2 * ref_ferr)
+    assert rel(grad.cpu().numpy(), g["grad_f64"]) <= max(1e-5, 4 * ref_gerr)
+    # accumulate semantics: a second call doubles both
+    eng.loss_grad(theta, x, t, 1.0 / n, ls, grad)
+    torch.cuda.synchronize()
+    assert abs(ls.sum().item() / n - 2 * loss) <= 1e-5 * abs(loss)
+    # vjp mode with gbar = 2 f / n equals the fused path
+    f = eng.residual_fwd(theta, x, t)
+    g2 = torch.zeros(eng.P, device=dev())
+    eng.residual_vjp(theta, x, t, 2.0 * f / n, g2)
+    torch.cuda.synchronize()
+    # (f is re-evaluated by a differently-contracted instantiation: at trained weights its fp32
+    #  cancellation noise shows up in the gradient, hence the reference-noise term)
+    assert rel(g2.cpu().numpy(), 0.5 * grad.cpu().numpy().astype(np.float64)) < max(2e-5, 4 * ref_gerr)
+
+
+@pytest.mark.parametrize("kname,kernel", KINDS)
+@pytest.mark.parametrize("name", ["kdv7_3sol_ckpt", "gnss_w100_ckpt", "burgers_9x20_xavier", "kdv7_bc_xavier"])
+def test_net_u_forward_and_vjp(name, kname, kernel):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eng = engine_for(g, kernel, eq="none")
+    o = Oracle("none", g["layers"].tolist(), g["lb"], g["ub"])
+    rng = np.random.default_rng(7)
+    for n in (1, 63, 64, 65, 257, 1000):
+        X = (g["lb"] + (g["ub"] - g["lb"]) * rng.random((n, 2))).astype(np.float32)
+        Xd = cu(X)
+        out = eng.forward(cu(g["theta"]), Xd, None)          # strided (N,2) input, like predict
+        der, _ = o.forward(g["theta"].astype(np.float64), X[:, 0], X[:, 1])
+        torch.cuda.synchronize()
+        assert rel(out.cpu().numpy(), der[:, :, 0]) < 1e-5, n
+        gb = rng.standard_normal((n, eng.nout)).astype(np.float32)
+        grad = torch.zeros(eng.P, device=dev())
+        eng.forward_vjp(cu(g["theta"]), Xd, None, cu(gb), grad)
+        _, gref = o.loss_grad(g["theta"].astype(np.float64), X[:, 0], X[:, 1], gbar=gb.astype(np.float64))
+        torch.cuda.synchronize()
+        assert rel(grad.cpu().numpy(), gref) < 1e-5, n
+
+
+@pytest.mark.parametrize("kname,kernel", KINDS)
+@pytest.mark.parametrize("name", ["kdv7_3sol_xavier", "ch_w64_xavier", "gnss_w50_xavier", "kdv5_xavier"])
+def test_ragged_sizes_against_oracle(name, kname, kernel):
+    """n that is not a multiple of the tile/wave size, including n = 1."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eng = engine_for(g, kernel)
+    o = Oracle(str(g["eq"]), g["layers"].tolist(), g["lb"], g["ub"])
+    rng = np.random.default_rng(11)
+    th64 = g["theta"].astype(np.float64)
+    for n in (1, 15, 17, 100, 700):
+        X = (g["lb"] + (g["ub"] - g["lb"]) * rng.random((n, 2))).astype(np.float32)
+        ls = torch.zeros(eng.nf, device=dev())
+        grad = torch.zeros(eng.P, device=dev())
+        eng.loss_grad(cu(g["theta"]), cu(X[:, 0]), cu(X[:, 1]), 1.0 / n, ls, grad)
+        lref, gref = o.loss_grad(th64, X[:, 0], X[:, 1], scale=1.0 / n)
+        torch.cuda.synchronize()
+        assert rel(ls.cpu().numpy(), lref) < 1e-5, n
+        assert rel(grad.cpu().numpy(), gref) < 1e-5, n
+
+
+@pytest.mark.parametrize("kname,kernel", KINDS)
+def test_full_size_properties(kname, kernel):
+    """BASELINE config sizes are too big for the oracle; use size-independent
+    properties: (a) additivity over shards: loss_grad(N) == loss_grad(first half) +
+    loss_grad(second half); (b) a 4096-point random subsample of f against the
+    oracle; (c) linearity of the vjp in the cotangent."""
+    g = np.load(os.path.join(GOLDEN, "kdv7_3sol_ckpt.npz"))
+    eng = engine_for(g, kernel)
+    N = 1_000_000 if kernel == KERNEL_MFMA else 200_000
+    rng = np.random.default_rng(1234)
+    X = (g["lb"] + (g["ub"] - g["lb"]) * rng.random((N, 2))).astype(np.float32)
+    x, t, theta = cu(X[:, 0]), cu(X[:, 1]), cu(g["theta"])
+    full = torch.zeros(eng.P + 1, device=dev())
+    eng.loss_grad(theta, x, t, 1.0 / N, full[eng.P:], full[:eng.P])
+    halves = torch.zeros(eng.P + 1, device=dev())
+    h = N // 2 + 13
+    eng.loss_grad(theta, x[:h], t[:h], 1.0 / N, halves[eng.P:], halves[:eng.P])
+    eng.loss_grad(theta, x[h:], t[h:], 1.0 / N, halves[eng.P:], halves[:eng.P])
+    torch.cuda.synchronize()
+    assert rel(halves.cpu().numpy(), full.cpu().numpy().astype(np.float64)) < 2e-5
+    sel = rng.choice(N, 4096, replace=False)
+    f = eng.residual_fwd(theta, x, t).cpu().numpy()[sel]
+    o = Oracle("kdv7_3sol", g["layers"].tolist(), g["lb"], g["ub"])
+    der64, f64 = o.forward(g["theta"].astype(np.float64), X[sel, 0], X[sel, 1])
+    scale = max(np.linalg.norm(der64[:, :, j]) for j in range(der64.shape[2]))
+    assert np.linalg.norm(f - f64) <= 1e-5 * scale
+    n2 = 50_000
+    g1 = cu(rng.standard_normal((n2, 1)))
+    g2 = cu(rng.standard_normal((n2, 1)))
+    o1 = torch.zeros(eng.P, device=dev()); o2 = torch.zeros(eng.P, device=dev()); o3 = torch.zeros(eng.P, device=dev())
+    eng.residual_vjp(theta, x[:n2], t[:n2], g1, o1)
+    eng.residual_vjp(theta, x[:n2], t[:n2], g2, o2)
+    eng.residual_vjp(theta, x[:n2], t[:n2], 0.5 * g1 - 2.0 * g2, o3)
+    torch.cuda.synchronize()
+    lin = (0.5 * o1 - 2.0 * o2).cpu().numpy().astype(np.float64)
+    assert rel(o3.cpu().numpy(), lin) < 1e-4
+
+
+def _load_theta(model, theta):
+    off = 0
+    with torch.no_grad():
+        for p in model.dnn.parameters():
+            n = p.numel()
+            p.copy_(torch.from_numpy(theta[off:off + n].reshape(tuple(p.shape))))
+            off += n
+
+
+@pytest.mark.parametrize("name,cls,kind", [
+    ("kdv7_3sol_ckpt", scripts.kdv7_3soliton.PI.PhysicsInformedNN, "pi"),
+    ("kdv7_sw_ckpt", scripts.kdv7_3soliton.sw.PhysicsInformedNN, "sw"),
+    ("kdv7_bc_xavier", scripts.kdv7_3soliton.bc.bcPhysicsInformedNN, "bc"),
+    ("burgers_ckpt", scripts.burgers.PI.PhysicsInformedNN, "burgers"),
+    ("ch_ckpt", scripts.camassa_holm.PI.PhysicsInformedNN, "pi"),
+    ("gnss_w100_ckpt", scripts.gnss.sw.PhysicsInformedNN, "gnss_sw"),
+])
+def test_class_backward_matches_reference(name, cls, kind):
+    """The drop-in class on the GPU vs the reference's own backward() (fp64 golden)."""
+    from test_host_logic import feed
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = cls(g["layers"].tolist(), g["lb"], g["ub"])
+    _load_theta(model, g["theta"])
+    feed(model, g, kind)
+    model.iter = 1
+    loss = model.backward()
+    torch.cuda.synchronize()
+    grad = torch.cat([p.grad.reshape(-1) for p in model.dnn.parameters()]).cpu().numpy()
+    ref_lerr = abs(float(g["loss_full32"]) - float(g["loss_full64"])) / float(g["loss_full64"])
+    ref_gerr = rel(g["grad_full32"], g["grad_full64"])
+    assert abs(loss.item() - g["loss_full64"]) / g["loss_full64"] <= max(1e-5, 4 * ref_lerr)
+    assert rel(grad, g["grad_full64"]) <= max(1e-5, 4 * ref_gerr)
+
+
+def test_predict_known_answer_error_txt(golden_dir):
+    """error.txt:101-102 — PI 73.pth on the 201x512 grid -> 3.743270e-01, on the GPU."""
+    g = np.load(os.path.join(golden_dir, "predict_kdv7_73.npz"))
+    m = scripts.kdv7_3soliton.PI.PhysicsInformedNN(g["layers"].tolist(), g["lb"], g["ub"])
+    _load_theta(m, g["theta"])
+    X, T = np.meshgrid(g["x"], g["t"])
+    X_star = np.hstack((X.flatten()[:, None], T.flatten()[:, None]))
+    u = m.predict(X_star)
+    u_star = g["uu"].flatten()[:, None]
+    err = np.linalg.norm(u_star - u, 2) / np.linalg.norm(u_star, 2)
+    assert abs(err - 3.743270e-01) < 5e-7
+    assert np.max(np.abs(u[g["sel"], 0] - g["u_pred_sel"])) < 2e-5 * np.max(np.abs(g["u_pred_sel"]))
+
+
+def test_short_training_run_decreases_loss():
+    g = np.load(os.path.join(GOLDEN, "burgers_9x20_xavier.npz"))
+    from test_host_logic import feed
+    m = scripts.burgers.PI.PhysicsInformedNN(g["layers"].tolist(), g["lb"], g["ub"])
+    _load_theta(m, g["theta"])
+    feed(m, g, "burgers")
+    m.iter = 1
+    l0 = m.backward().item()
+    m.train(50, LBFGS_max_iter=20)
+    m.optimizer_Adam.zero_grad()
+    l1 = m.backward().item()
+    assert l1 < l0

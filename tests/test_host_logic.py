@@ -1,0 +1,161 @@
+"""CPU: host-side logic of pde_amd (no kernels): the drop-in class composes the
+same loss as the reference's backward(), keeps the reference's state-dict keys,
+and the C-ABI library exports what include/pinnjet.h declares.  Compute is
+supplied by a TEST-ONLY oracle engine (tests/oracle_engine.py)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from oracle_engine import install
+from pde_amd import scripts
+from pde_amd._native import LIB_PATH, SYMBOLS
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+def load_theta(model, theta):
+    off = 0
+    with torch.no_grad():
+        for p in model.dnn.parameters():
+            n = p.numel()
+            p.copy_(torch.from_numpy(theta[off:off + n].reshape(tuple(p.shape))))
+            off += n
+
+
+def make_model(g, cls):
+    model = install(cls)(g["layers"].tolist(), g["lb"], g["ub"])
+    load_theta(model, g["theta"])
+    return model
+
+
+def flat_grad(model):
+    return torch.cat([p.grad.reshape(-1) for p in model.dnn.parameters()]).numpy()
+
+
+CASES = [
+    ("kdv7_3sol_xavier", scripts.kdv7_3soliton.PI.PhysicsInformedNN, "pi"),
+    ("kdv7_sw_ckpt", scripts.kdv7_3soliton.sw.PhysicsInformedNN, "sw"),
+    ("kdv7_bc_xavier", scripts.kdv7_3soliton.bc.bcPhysicsInformedNN, "bc"),
+    ("kdv5_xavier", scripts.kdv5_1soliton.PI.PhysicsInformedNN, "pi"),
+    ("burgers_9x20_xavier", scripts.burgers.PI.PhysicsInformedNN, "burgers"),
+    ("ch_w64_xavier", scripts.camassa_holm.PI.PhysicsInformedNN, "pi"),
+    ("ch_bc_xavier", scripts.camassa_holm_bc.PI.PhysicsInformedNN, "pi"),
+    ("gnss_w50_xavier", scripts.gnss.PI.PhysicsInformedNN, "gnss"),
+    ("gnss_w100_ckpt", scripts.gnss.sw.PhysicsInformedNN, "gnss_sw"),
+]
+
+
+def feed(model, g, kind):
+    Xf = np.stack([g["x"], g["t"]], axis=1).astype(np.float64)
+    d = {k[5:]: g[k] for k in g.files if k.startswith("data_")}
+    if kind == "pi":
+        model.set_training_data(d["x0"], d["u0"], d["tb"], Xf)
+    elif kind == "burgers":
+        model.set_training_data(d["x0"], d["u0"], d["tb"], Xf, 0.01 / np.pi)
+    elif kind == "sw":
+        model.set_training_data(d["x0"], d["u0"], d["tb"], Xf, d["X_prev"], d["u_prev"])
+    elif kind == "bc":
+        Xh = np.concatenate([d["x1"], d["t1"]], axis=1)
+        model.set_training_data(d["x0"], d["u0"], float(d["t0"][0, 0]), d["u1"], d["tb"], Xf, Xh)
+    elif kind == "gnss":
+        model.set_training_data(d["x0"], d["u0"], d["v0"], d["tb"], Xf)
+    elif kind == "gnss_sw":
+        model.set_training_data(d["x0"], d["u0"], d["v0"], d["tb"], Xf, d["X_prev"], d["u_prev"], d["v_prev"])
+
+
+@pytest.mark.parametrize("name,cls,kind", CASES)
+def test_backward_matches_reference_backward(name, cls, kind):
+    """loss and flat gradient of the full backward() vs the reference's own
+    backward() (fp64 golden), fp32 tolerance."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    model = make_model(g, cls)
+    feed(model, g, kind)
+    model.iter = 1
+    loss = model.backward()
+    ref_gerr = rel(g["grad_full32"], g["grad_full64"])
+    assert abs(loss.item() - g["loss_full64"]) <= max(1e-5, 4 * abs(g["loss_full32"] - g["loss_full64"]) / g["loss_full64"]) * g["loss_full64"]
+    assert rel(flat_grad(model), g["grad_full64"]) <= max(1e-5, 4 * ref_gerr)
+    assert model.iter == 2
+
+
+def test_net_f_is_differentiable_like_the_reference():
+    g = np.load(os.path.join(GOLDEN, "gnss_w50_xavier.npz"))
+    model = make_model(g, scripts.gnss.PI.PhysicsInformedNN)
+    x = torch.tensor(g["x"][:, None])
+    t = torch.tensor(g["t"][:, None])
+    fu, fv = model.net_f(x, t)
+    assert fu.shape == (len(g["x"]), 1)
+    loss = torch.mean(torch.square(fu)) + torch.mean(torch.square(fv))
+    loss.backward()
+    assert abs(loss.item() - g["loss_f64"]) < 1e-5 * g["loss_f64"]
+    assert rel(flat_grad(model), g["grad_f64"]) < 1e-5
+    f = np.concatenate([fu.detach().numpy(), fv.detach().numpy()], axis=1)
+    assert rel(f, g["f64"]) < 1e-5
+
+
+def test_state_dict_keys_and_roundtrip(tmp_path):
+    g = np.load(os.path.join(GOLDEN, "kdv7_3sol_ckpt.npz"))
+    cls = install(scripts.kdv7_3soliton.PI.PhysicsInformedNN)
+    cls.base_dir = str(tmp_path)
+    m = cls([2, 50, 50, 50, 50, 1], g["lb"], g["ub"])
+    keys = list(m.dnn.state_dict().keys())
+    assert keys == ["1.layers.layer_%d.%s" % (i, k) for i in range(5) for k in ("weight", "bias")]
+    load_theta(m, g["theta"])
+    m.save_model("a.pth")
+    m2 = cls([2, 50, 50, 50, 50, 1], g["lb"], g["ub"])
+    m2.load_model("a.pth")
+    assert torch.equal(m2.dnn.flat_theta(), m.dnn.flat_theta())
+    # parameters stay views into the flat buffer after load_state_dict
+    assert m2.dnn.param_list[0].data_ptr() == m2.dnn.flat_theta().data_ptr()
+    # sliding-window warm start copies the weights (7kdv/sw-73.py:83-85)
+    sw = install(scripts.kdv7_3soliton.sw.PhysicsInformedNN)
+    m3 = sw([2, 50, 50, 50, 50, 1], g["lb"], g["ub"], m)
+    assert torch.equal(m3.dnn.flat_theta(), m.dnn.flat_theta())
+
+
+def test_predict_known_answer(golden_dir):
+    """Burgers checkpoint + burgers256*100.mat -> rel-L2 3.153112e-03."""
+    g = np.load(os.path.join(golden_dir, "predict_burgers.npz"))
+    m = install(scripts.burgers.PI.PhysicsInformedNN)(g["layers"].tolist(), g["lb"], g["ub"])
+    load_theta(m, g["theta"])
+    X, T = np.meshgrid(g["x"], g["t"])
+    X_star = np.hstack((X.flatten()[:, None], T.flatten()[:, None]))
+    u = m.predict(X_star)
+    assert u.shape == (X_star.shape[0], 1)
+    u_star = g["uu"].flatten()[:, None]
+    err = np.linalg.norm(u_star - u, 2) / np.linalg.norm(u_star, 2)
+    assert abs(err - float(g["err_ref"])) < 2e-6
+
+
+def test_adam_step_runs_and_decreases_loss():
+    g = np.load(os.path.join(GOLDEN, "burgers_9x20_xavier.npz"))
+    m = make_model(g, scripts.burgers.PI.PhysicsInformedNN)
+    feed(m, g, "burgers")
+    m.train(3, LBFGS_max_iter=0)
+    assert m.iter == 3
+
+
+@pytest.mark.skipif(not os.path.exists(LIB_PATH), reason="libpinnjet.so not built")
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "pinnjet.h")).read()
+    declared = set(re.findall(r"\b(pinn_[a-z_]+)\s*\(", hdr))
+    assert declared == set(SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+    lib.pinn_error_string.restype = ctypes.c_char_p
+    assert lib.pinn_error_string(0) == b"ok"
+    # invalid descriptors are rejected without touching the GPU
+    from pde_amd._native import PinnDesc
+    d = PinnDesc()
+    h = ctypes.c_void_p()
+    assert lib.pinn_create(ctypes.byref(d), ctypes.byref(h)) == -1
+    assert lib.pinn_create(None, ctypes.byref(h)) == -4
