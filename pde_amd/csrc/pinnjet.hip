@@ -143,6 +143,41 @@ int run_valu(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, fl
     return PINN_OK;
 }
 
+#ifdef PINN_WITH_MFMA
+// one residual-type call on the MFMA path
+int run_mfma(MfmaPlan &pl, const KDesc &kd, int eq, int mode, CallArgs a, float *grad_accum, float *loss_accum,
+             hipStream_t st)
+{
+    int K, KT, nf;
+    if (eq_orders(eq, kd.nout, &K, &KT, &nf)) return PINN_ERR_INVALID_DESC;
+    const int J = K + 1 + KT;
+    const long long ntiles = (a.n + 15) / 16;
+    const long long need_blocks = (ntiles + MFMA_WAVES - 1) / MFMA_WAVES;
+    const int grid = (int)(need_blocks < pl.grid ? need_blocks : pl.grid);
+    int rc;
+    if (mode != MODE_FWD) {
+        const size_t per_wave = (size_t)(kd.n_lin - 1) * 2 * pl.NT * J * 256 * sizeof(float);
+        rc = ensure(&pl.stash, &pl.stash_bytes, per_wave * grid * MFMA_WAVES);
+        if (rc) return rc;
+        rc = ensure(&pl.slab, &pl.slab_bytes, (size_t)grid * (kd.P + 2) * sizeof(float));
+        if (rc) return rc;
+        a.slab = pl.slab;
+    }
+    switch (mode) {
+    case MODE_FWD:  rc = launch_mfma_eq<MODE_FWD>(pl, eq, kd, a, grid, st); break;
+    case MODE_VJP:  rc = launch_mfma_eq<MODE_VJP>(pl, eq, kd, a, grid, st); break;
+    default:        rc = launch_mfma_eq<MODE_LOSS>(pl, eq, kd, a, grid, st); break;
+    }
+    if (rc) return rc;
+    if (mode != MODE_FWD) {
+        const int rb = (kd.P + 2 + 63) / 64;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(rb), dim3(256), 0, st, pl.slab, grid, kd.P, grad_accum, loss_accum, nf);
+        if (hipGetLastError() != hipSuccess) return PINN_ERR_HIP;
+    }
+    return PINN_OK;
+}
+#endif
+
 int run(pinn_handle *h, int eq, int mode, const CallArgs &a, float *grad_accum, float *loss_accum, void *stream)
 {
     if (!h) return PINN_ERR_NULL;

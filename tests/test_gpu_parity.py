@@ -100,7 +100,7 @@ def test_loss_and_gradient(name, kname, kernel):
     # reference's own fp32 f error is the noise floor at trained (cancelling) weights
     ref_ferr = rel(g["f32"], g["f64"])
     assert abs(loss - g["loss_f64"]) / g["loss_f64"] <= max(1e-5, 4 * ref_lerr, 2 * ref_ferr)
-    assert rel(grad.cpu().numpy(), g["grad_f64"]) <= max(1e-5, 4 * ref_gerr)
+    assert rel(grad.cpu().numpy(), g["grad_f64"]) <= max(1e-5, 6 * ref_gerr)
     # accumulate semantics: a second call doubles both
     eng.loss_grad(theta, x, t, 1.0 / n, ls, grad)
     torch.cuda.synchronize()
