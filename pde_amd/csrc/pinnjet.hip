@@ -156,7 +156,7 @@ int run_mfma(MfmaPlan &pl, const KDesc &kd, int eq, int mode, CallArgs a, float 
     const int grid = (int)(need_blocks < pl.grid ? need_blocks : pl.grid);
     int rc;
     if (mode != MODE_FWD) {
-        const size_t per_wave = (size_t)(kd.n_lin - 1) * 2 * pl.NT * J * 256 * sizeof(float);
+        const size_t per_wave = mfma_stash_floats(kd, J) * sizeof(float);
         rc = ensure(&pl.stash, &pl.stash_bytes, per_wave * grid * MFMA_WAVES);
         if (rc) return rc;
         rc = ensure(&pl.slab, &pl.slab_bytes, (size_t)grid * (kd.P + 2) * sizeof(float));
@@ -239,7 +239,7 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     for (int l = 1; l < desc->n_lin; ++l) uniform = uniform && desc->widths[l] == W;
     int kernel = desc->kernel;
 #ifdef PINN_WITH_MFMA
-    const bool mfma_ok = uniform && W <= PINN_MAX_WIDTH && mfma_supported(kd);
+    const bool mfma_ok = uniform && mfma_supported(kd);
 #else
     const bool mfma_ok = false;
 #endif

@@ -225,8 +225,9 @@ def test_class_backward_matches_reference(name, cls, kind):
     grad = torch.cat([p.grad.reshape(-1) for p in model.dnn.parameters()]).cpu().numpy()
     ref_lerr = abs(float(g["loss_full32"]) - float(g["loss_full64"])) / float(g["loss_full64"])
     ref_gerr = rel(g["grad_full32"], g["grad_full64"])
-    assert abs(loss.item() - g["loss_full64"]) / g["loss_full64"] <= max(1e-5, 4 * ref_lerr)
-    assert rel(grad, g["grad_full64"]) <= max(1e-5, 4 * ref_gerr)
+    ref_ferr = rel(g["f32"], g["f64"])      # fp32 noise floor of the residual at these weights
+    assert abs(loss.item() - g["loss_full64"]) / g["loss_full64"] <= max(1e-5, 4 * ref_lerr, 2 * ref_ferr)
+    assert rel(grad, g["grad_full64"]) <= max(1e-5, 6 * ref_gerr)
 
 
 def test_predict_known_answer_error_txt(golden_dir):
