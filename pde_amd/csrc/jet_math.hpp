@@ -26,12 +26,21 @@ constexpr int MAXOUT = 2;
 
 __device__ __forceinline__ float fast_tanh(float x)
 {
-    // tanh(x) = sign(x) * (1 - e) / (1 + e), e = exp(-2|x|).  |abs err| < 2e-7:
-    // v_exp_f32 and v_rcp_f32 are ~1 ulp; for |x| < 0.04 switch to the odd
-    // series to keep the relative error small where 1-e cancels.
+    // Branch-free tanh(x) = sign(x) (1 - e)/(1 + e), e = exp(-2|x|), to ~1-2 ulp:
+    //  * the exponent -2|x| log2(e) is formed as hi + lo (fma residual + low word of the constant) so
+    //    that v_exp_f32's argument rounding does not cost |x| ulps;
+    //  * the quotient gets one Newton step on top of v_rcp_f32;
+    //  * for |x| < 0.04 the odd series avoids the cancellation in 1 - e.
     const float ax = fabsf(x);
-    const float e = __expf(-2.0f * ax);
-    float r = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float c_hi = -2.885390043258667f, c_lo = -3.851960541e-8f;   // -2/ln2 = c_hi + c_lo
+    const float hi = ax * c_hi;
+    const float lo = fmaf(ax, c_hi, -hi) + ax * c_lo;
+    float e = __builtin_amdgcn_exp2f(hi);
+    e = fmaf(e, lo * 0.6931471806f, e);
+    const float num = 1.0f - e, den = 1.0f + e;
+    const float rc = __builtin_amdgcn_rcpf(den);
+    float r = num * rc;
+    r = fmaf(fmaf(-den, r, num), rc, r);
     const float x2 = x * x;
     const float s = ax * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.05396825f * x2)));
     r = ax < 0.04f ? s : r;
@@ -45,7 +54,7 @@ template <int K, int KT>
 __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float (&y)[K + 1 + KT],
                                              float (&w)[K + 1])
 {
-    y[0] = tanhf(z[0]);
+    y[0] = fast_tanh(z[0]);   // branch-free: keeps a whole tile's tanh work in one scheduling region
     w[0] = fmaf(-y[0], y[0], 1.0f);
 #pragma unroll
     for (int k = 1; k <= K; ++k) {

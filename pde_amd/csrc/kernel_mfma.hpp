@@ -134,6 +134,10 @@ __device__ __forceinline__ void sb_store1(__amdgpu_buffer_rsrc_t rs, int voff, i
 {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rs, voff, soff_floats * 4, 0);
 }
+__device__ __forceinline__ f32x4 sb_load4(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats)
+{
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_floats * 4, 0));
+}
 __device__ __forceinline__ float sb_load1(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff_floats * 4, 0));
@@ -141,6 +145,29 @@ __device__ __forceinline__ float sb_load1(__amdgpu_buffer_rsrc_t rs, int voff, i
 
 #define PINN_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define PINN_SB() __builtin_amdgcn_sched_barrier(0)
+
+// MFMA block of the forward GEMM for one output tile: acc[j] = bias + sum_{Ti,r} W-frag * A[Ti][j][r]
+template <int W, int J>
+__device__ __forceinline__ void fwd_mma_tile(const float *img, int To, int p, int q,
+                                             const f32x4 (&A)[WidthCfg<W>::NT][J], f32x4 (&acc)[J])
+{
+    typedef WidthCfg<W> C;
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    acc[0] = *(const f32x4 *)&img[C::O_BIAS + 16 * To + 4 * q];
+#pragma unroll
+    for (int Ti = 0; Ti < C::NT; ++Ti) {
+        // A fragment: lane (m = p, q) holds W[16To + m][16Ti + 4q + r], r = 0..3
+        const f32x4 wf = *(const f32x4 *)&img[(16 * To + p) * C::S + 16 * Ti + 4 * q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (16 * Ti + r < W) {     // compile-time: k-steps that only hit padding are dropped
+#pragma unroll
+                for (int j = 0; j < J; ++j) acc[j] = mfma4(wf[r], A[Ti][j][r], acc[j]);
+            }
+        }
+    }
+}
 
 template <int EQ, int W, int MODE>
 __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, float *stash)
@@ -296,6 +323,10 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             for (int e = 0; e < RR; ++e)
 #pragma unroll
                 for (int j = 0; j < J; ++j) Bt[e][j] = 0.0f;
+            // software pipeline: the MFMA block of output tile To+1 is issued before the VALU work
+            // (tail neurons, tanh jets) of tile To, so the matrix pipe runs under the vector work
+            f32x4 acc[2][J];
+            fwd_mma_tile<W, J>(img, 0, p, q, A, acc[0]);
             if (TAIL) {
                 // tail outputs: every lane sums over its 4*NT tiled inputs, then across the lane quads
 #pragma unroll
@@ -332,39 +363,25 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             }
 #pragma unroll
             for (int To = 0; To < NT; ++To) {
-                f32x4 acc[J];
-#pragma unroll
-                for (int j = 0; j < J; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-                acc[0] = *(const f32x4 *)&img[C::O_BIAS + 16 * To + 4 * q];
-#pragma unroll
-                for (int Ti = 0; Ti < NT; ++Ti) {
-                    // A fragment: lane (m = p, q) holds W[16To + m][16Ti + 4q + r], r = 0..3
-                    const f32x4 wf = *(const f32x4 *)&img[(16 * To + p) * S + 16 * Ti + 4 * q];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (16 * Ti + r < W) {     // compile-time: k-steps that only hit padding are dropped
-#pragma unroll
-                            for (int j = 0; j < J; ++j) acc[j] = mfma4(wf[r], A[Ti][j][r], acc[j]);
-                        }
-                    }
-                }
+                if (To + 1 < NT) fwd_mma_tile<W, J>(img, To + 1, p, q, A, acc[(To + 1) & 1]);
+                f32x4 (&ac)[J] = acc[To & 1];
                 if (TAIL) {
 #pragma unroll
                     for (int e = 0; e < R; ++e) {
                         const f32x4 wc = *(const f32x4 *)&img[C::O_WTC + e * NM + 16 * To + 4 * q];
 #pragma unroll
-                        for (int j = 0; j < J; ++j) acc[j] += wc * At[e][j];
+                        for (int j = 0; j < J; ++j) ac[j] += wc * At[e][j];
                     }
                 }
                 if (MODE != MODE_FWD) {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) sb_store4(srs, vnat, zs + (To * J + j) * TILE, acc[j]);
+                    for (int j = 0; j < J; ++j) sb_store4(srs, vnat, zs + (To * J + j) * TILE, ac[j]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float z[J], y[J], w[K + 1];
 #pragma unroll
-                    for (int j = 0; j < J; ++j) z[j] = acc[j][r];
+                    for (int j = 0; j < J; ++j) z[j] = ac[j][r];
                     tanh_jet_fwd<K, KT>(z, y, w);
 #pragma unroll
                     for (int j = 0; j < J; ++j) B[To][j][r] = y[j];
@@ -527,6 +544,12 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
 #pragma unroll
             for (int j = 0; j < J; ++j) Ct[e][j] = 0.0f;
 
+        f32x4 zq[2][J], yq[2][J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            zq[0][j] = sb_load4(srs, vnat, (NH - 1) * LAYER_STASH + (0 * J + j) * TILE);
+            yq[0][j] = sb_load4(srs, vnat, (NH - 1) * LAYER_STASH + ZY + (0 * J + j) * TILE);
+        }
         for (int hl = NH - 1; hl >= 0; --hl) {
             const int zs = hl * LAYER_STASH;
             const bool above = hl < NH - 1;     // Linear layer hl+1 (hidden->hidden) sits above
@@ -563,34 +586,25 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                         }
                 }
             }
-            // tiled neurons: per (tile, r) the lane needs z/y of ONE neuron = 2*J dwords out of the
-            // [point][neuron] images (stride-16-B gathers, 8 lines per instruction: cheap next to the
-            // tanh reverse).  The next step's dwords are in flight while the current one is processed;
-            // loading whole f32x4 tiles here costs 4x the registers and spills.
-            float zn[2][J], yn[2][J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                zn[0][j] = sb_load1(srs, vnat, zs + (0 * J + j) * TILE);
-                yn[0][j] = sb_load1(srs, vnat, zs + ZY + (0 * J + j) * TILE);
-            }
+            // tiled neurons: z/y tiles of this layer come back from the stash as f32x4 rows; tile T+1 is
+            // in flight while tile T is processed, and tile 0 of the NEXT layer down is requested before
+            // the MFMA phases below so that its latency hides under them.
 #pragma unroll
             for (int T = 0; T < NT; ++T) {
+                if (T + 1 < NT) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        zq[(T + 1) & 1][j] = sb_load4(srs, vnat, zs + ((T + 1) * J + j) * TILE);
+                        yq[(T + 1) & 1][j] = sb_load4(srs, vnat, zs + ZY + ((T + 1) * J + j) * TILE);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int step = T * 4 + r, cur = step & 1, nxt = cur ^ 1;
-                    if (step + 1 < NT * 4) {
-                        const int T2 = (step + 1) >> 2, r2 = (step + 1) & 3;
+                    float z[J], y[J], w[K + 1], yb[J], zb[J];
 #pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            zn[nxt][j] = sb_load1(srs, vnat, zs + (T2 * J + j) * TILE + r2);
-                            yn[nxt][j] = sb_load1(srs, vnat, zs + ZY + (T2 * J + j) * TILE + r2);
-                        }
-                    }
-                    float w[K + 1], yb[J], zb[J];
-#pragma unroll
-                    for (int j = 0; j < J; ++j) yb[j] = G[T][j][r];
-                    w_from_y<K>(yn[cur], w);
-                    tanh_jet_bwd<K, KT>(zn[cur], yn[cur], w, yb, zb);
+                    for (int j = 0; j < J; ++j) { z[j] = zq[T & 1][j][r]; y[j] = yq[T & 1][j][r]; yb[j] = G[T][j][r]; }
+                    w_from_y<K>(y, w);
+                    tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
 #pragma unroll
                     for (int j = 0; j < J; ++j) G[T][j][r] = zb[j];
                     const int n = 16 * T + 4 * q + r;
@@ -603,7 +617,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                         for (int e = 0; e < R; ++e) {
                             float v = 0.0f;
 #pragma unroll
-                            for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], yn[cur][j], v);
+                            for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], y[j], v);
                             v = row_sum16(v);
                             if (p == 0) atomicAdd(&gw_above[(NM + e) * W + n], v);
                         }
@@ -612,6 +626,14 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                 }
 #pragma unroll
                 for (int j = 0; j < J; ++j) park(G[T][j]);
+            }
+            if (hl > 0) {
+                const int zn = (hl - 1) * LAYER_STASH;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    zq[0][j] = sb_load4(srs, vnat, zn + (0 * J + j) * TILE);
+                    yq[0][j] = sb_load4(srs, vnat, zn + ZY + (0 * J + j) * TILE);
+                }
             }
             if (hl == 0) break;
 
