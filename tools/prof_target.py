@@ -17,7 +17,11 @@ ap.add_argument("--workload", default="kdv7")
 ap.add_argument("--n", type=int, default=0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--kernel", type=int, default=0)
+ap.add_argument("--lib", default="", help="alternative libpinnjet.so (development builds)")
 args = ap.parse_args()
+if args.lib:
+    import pde_amd._native as _nat
+    _nat.LIB_PATH = os.path.abspath(args.lib)
 w = WORKLOADS[args.workload]
 n = args.n or w["n"]
 dev = torch.device("cuda", 0)
