@@ -1,34 +1,41 @@
 // FP32-MFMA kernels: one wavefront owns a tile of 16 collocation points and
 // carries the jets of a whole hidden layer in registers.
 //
-// Layout (v_mfma_f32_16x16x4_f32, MI355X guide §3): for a 16x16 tile the
-// accumulator of lane l holds rows 4*(l>>4)+r (r=0..3), column l&15.  NEURONS sit
-// on rows, POINTS on columns:
+// What the MI355X measurements behind this design say (tools/ubench/README.md):
+//  * v_mfma_f32_16x16x4_f32 executes on the same FMA lanes as the FP32 VALU: MFMA time and VALU time
+//    ADD, within a wave and across the waves of a SIMD.  Nothing is gained by software-pipelining
+//    MFMAs against VALU work; what counts is the instruction count and not stalling.
+//  * With one wave per SIMD every latency (dependent VALU issue, LDS round trips, stash loads, MFMA
+//    results) is exposed; with two waves per SIMD the other wave fills the gaps.  So: 8 waves per
+//    workgroup, at most 256 registers per wave, and NO register spills.
+//  * A 64-lane ds_add_f32 costs 192 cycles, serialised over the CU.  The weight-gradient tiles are
+//    therefore accumulated by a plain read-add-write of a shared LDS image under a per-layer lock;
+//    LDS float atomics are only used with <= 4 active lanes (bias / tail entries).
+//
+// Layout (v_mfma_f32_16x16x4_f32, MI355X guide section 3): for a 16x16 tile the accumulator of lane
+// l holds rows 4*(l>>4)+r (r=0..3), column l&15.  NEURONS sit on rows, POINTS on columns:
 //     lane (p = l&15, q = l>>4), register r  <->  neuron 16*T + 4*q + r, point p
-// for neuron tile T.  An activation set is  v[T][k][r]  (k = jet component).
+// for neuron tile T.  An activation set is  A[T][k][r]  (k = jet component): NT*J*4 registers.
 //
-//  * forward  Z^T[o][p] = sum_i W[o][i] Y^T[i][p]:  A = W fragment, B = the
-//    previous layer's accumulator registers used directly as the B operand
-//    (k-step (Ti, r) covers input neurons 16Ti + 4q + r; the A fragment is read
-//    from LDS in the matching order), so activations never leave registers
-//    between layers;
-//  * adjoint  Yb^T[i][p] = sum_o W[o][i] Zb^T[o][p]: same trick with W^T;
-//  * weight gradient  Wb[o][i] = sum_{p,k} Zb_k[o][p] Y_k[i][p]: the reduction
-//    runs over points, which sit on lanes, so both operands are needed
-//    transposed: Zb goes through a 1-KiB-per-tile LDS staging image, Y is read
-//    back from the stash the forward sweep wrote in [point][neuron] order, whose
-//    transposed read is a plain coalesced dword load.
+//  * forward  Z^T[o][p] = sum_i W[o][i] Y^T[i][p]: A operand = W fragment from LDS, B operand = the
+//    previous layer's registers used directly (k-step (Ti, r) covers input neurons 16Ti + 4q + r).
+//    The GEMM runs one jet component at a time and OVERWRITES that component in place (a linear layer
+//    never mixes components), so a layer needs NT*J*4 + NT*4 registers, not twice NT*J*4;
+//  * adjoint  Yb^T[i][p] = sum_o W[o][i] Zb^T[o][p]: same, with W^T fragments;
+//  * weight gradient  Wb[o][i] = sum_{p,k} Zb_k[o][p] Y_k[i][p]: the reduction runs over points, which
+//    sit on lanes, so both operands are needed transposed.  Zb goes through a padded LDS staging
+//    image; Y comes back from the stash, which stores y as [neuron][point] so that the transposed
+//    fragment is one b128 load per lane (MFMA k-index kk of step s  <->  point 4*kk + s).
 //
-// Widths that are 16*NT + R with 1 <= R <= 4 (the reference's width 50 = 48 + 2)
-// do not pad up to the next tile: the R "tail" neurons are carried per lane on
-// the VALU (replicated over the four lane quads), which removes the padding
-// MFMAs (width 50: 972 instead of 1584 MFMAs per layer and tile) and a quarter
-// of the register footprint.
+// Widths that are 16*NT + R with 1 <= R <= 4 (the reference's width 50 = 48 + 2) do not pad up to the
+// next tile: the R "tail" neurons are carried per lane on the VALU (replicated over the four lane
+// quads).
 //
-// Weights stay resident in LDS; the weight gradient is accumulated per
-// workgroup in LDS and leaves as one partial slab per workgroup (summed in a
-// fixed order by k_reduce_slabs).  tanh jets / residuals: jet_math.hpp.
-// Reference semantics as kernel_valu.hpp.
+// Stash (global, private per wave, re-used every tile): per tanh layer  z main | y main | z tail | y tail.
+// z of the first layer is recomputed (it is affine in x,t) and y of the last tanh layer never leaves
+// registers, so neither is written.
+//
+// tanh jets / residuals: jet_math.hpp.  Reference semantics as kernel_valu.hpp.
 #pragma once
 #include "jet_math.hpp"
 #include "pinn_common.hpp"
@@ -37,8 +44,14 @@ namespace pinn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MFMA_BLOCK = 256;
+#ifndef PINN_MFMA_BLOCK
+#define PINN_MFMA_BLOCK 512
+#endif
+constexpr int MFMA_BLOCK = PINN_MFMA_BLOCK;
 constexpr int MFMA_WAVES = MFMA_BLOCK / 64;
+constexpr int MFMA_LDS_LIMIT = 160 * 1024;
+constexpr int STAGE_ROW = 20;                  // floats per point row of the staging image (16 + pad: no bank conflicts)
+constexpr int STAGE_TILE = 16 * STAGE_ROW;
 
 template <int W> struct WidthCfg {
     static constexpr int REM = W % 16;
@@ -68,8 +81,14 @@ struct MfmaLayout {   // offsets in floats into dynamic LDS
     int hh;           // hidden->hidden images, layer l (1..n_lin-2) at hh + (l-1)*HH
     int io;           // first/last layer block
     int zero_end;     // everything before this is zero-filled then populated
-    int gacc;         // [P+2]
-    int stage;        // per wave NT*256
+    // gradient accumulators.  Everything except the NM x NM main block of the hidden->hidden weight
+    // gradients is small and is accumulated with few-lane LDS atomics in the compact block `gs`:
+    //   [W0: 2W][b0: W] | per hidden layer l: [b_l: W][tail rows: R x W][tail cols: NM x R] | [Wout][bout] | [loss: 2]
+    int gs, gs_hid, gs_hid_stride, gs_out, gs_loss, gs_size;
+    int wimg;         // main blocks as MFMA accumulator images [l-1][To][Ti][lane][r] (tile = 256 floats)
+    int locks;        // one int per hidden->hidden layer
+    int stage;        // per wave NT*STAGE_TILE
+    int xt;           // per wave [2][64]: the scaled coordinates of the tile's points, parked between the sweeps
     int total;
 };
 
@@ -81,15 +100,51 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     L.hh = off; off += (d.n_lin - 2) * C::HH;
     L.io = off; off += C::IO;
     L.zero_end = off;
-    L.gacc = off; off += ((d.P + 2 + 3) / 4) * 4;
-    L.stage = off; off += MFMA_WAVES * C::NT * 256;
+    L.gs = off;
+    L.gs_hid = 3 * W;
+    L.gs_hid_stride = W + C::R * W + C::NM * C::R;
+    L.gs_out = L.gs_hid + (d.n_lin - 2) * L.gs_hid_stride;
+    L.gs_loss = L.gs_out + d.nout * W + d.nout;
+    L.gs_size = ((L.gs_loss + 2 + 3) / 4) * 4;
+    off += L.gs_size;
+    L.wimg = off; off += (d.n_lin - 2) * C::NT * C::NT * 256;
+    L.locks = off; off += ((d.n_lin - 2 + 3) / 4) * 4 + 4;
+    L.stage = off; off += MFMA_WAVES * C::NT * STAGE_TILE;
+    L.xt = off; off += MFMA_WAVES * 128;
     L.total = off;
     return L;
 }
 
+// Timing ablations for kernel development (tools/ablate.sh): -DPINN_ABL_x=1 turns one cost centre into a
+// never-taken branch, so the build measures what that part costs.  Results are wrong with any of them on.
+#ifndef PINN_ABL_WACC
+#define PINN_ABL_WACC 0      // lock + read-add-write of the weight-gradient images
+#endif
+#ifndef PINN_ABL_SATOM
+#define PINN_ABL_SATOM 0     // the small (bias / tail / first / last layer) LDS atomics
+#endif
+#ifndef PINN_ABL_STLOAD
+#define PINN_ABL_STLOAD 0    // stash loads
+#endif
+#ifndef PINN_ABL_STSTORE
+#define PINN_ABL_STSTORE 0   // stash stores
+#endif
+#ifndef PINN_ABL_MFMA
+#define PINN_ABL_MFMA 0      // the MFMAs themselves
+#endif
+#ifndef PINN_CUT
+#define PINN_CUT 0
+#endif
+#define PINN_ADD_S(addr, v) do { if (!PINN_ABL_SATOM || rt_false) atomicAdd(addr, v); } while (0)
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
+#if PINN_ABL_MFMA
+    c[0] += a * b;
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // sum over the 16 lanes of a DPP row (= the 16 points of the tile); every lane gets the sum
@@ -115,58 +170,66 @@ __device__ __forceinline__ float quad_rows_sum(float v)
     return v;
 }
 
-// Park a value in the accumulator half of the unified register file.  VALU instructions can only
-// address the 256 architectural VGPRs; the big per-layer activation sets are touched by MFMAs (which
-// read/write AGPRs directly) most of the time, so pinning them there keeps the VALU working set small
-// (no scratch spills); a VALU use costs one v_accvgpr_read.
-__device__ __forceinline__ void park(f32x4 &v) { asm volatile("" : "+a"(v)); }
-
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// Stash accesses go through a buffer descriptor: one shared per-lane VGPR offset plus a SCALAR offset
-// per access.  With plain pointers the compiler materialises one loop-invariant VGPR address per
-// access (the constant part exceeds the 13-bit immediate), hoists all of them out of the tile loop and
-// spills them.
+// Stash accesses go through a buffer descriptor: one per-lane VGPR offset plus a SCALAR offset per
+// access, so no per-access 64-bit address is ever materialised (or hoisted and spilled).
 __device__ __forceinline__ void sb_store4(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats, f32x4 v)
 {
+#if PINN_ABL_STSTORE
+    if (voff >= 0) return;
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff_floats * 4, 0);
 }
 __device__ __forceinline__ void sb_store1(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats, float v)
 {
+#if PINN_ABL_STSTORE
+    if (voff >= 0) return;
+#endif
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rs, voff, soff_floats * 4, 0);
 }
 __device__ __forceinline__ f32x4 sb_load4(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats)
 {
+#if PINN_ABL_STLOAD
+    if (voff >= 0) { const float v = __int_as_float(voff + soff_floats); return (f32x4){v, v, v, v}; }
+#endif
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_floats * 4, 0));
 }
 __device__ __forceinline__ float sb_load1(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats)
 {
+#if PINN_ABL_STLOAD
+    if (voff >= 0) return __int_as_float(voff + soff_floats);
+#endif
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff_floats * 4, 0));
 }
 
 #define PINN_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define PINN_SB() __builtin_amdgcn_sched_barrier(0)
+// Boundary between two jet components of an in-place GEMM: nothing is scheduled across it and LDS
+// contents are re-read after it, so the weight fragments are NOT kept in registers over the whole
+// component loop (36+ registers that the in-place scheme exists to save); LDS reads are cheap.
+#define PINN_JB() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// Pin a value: it is computed before this point and not re-derived later.  Without it LLVM sinks the
+// unrolled jet arithmetic of a neuron past the exec-masked atomics into the block of its first use
+// (a whole phase later) and spills the inputs instead.
+__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
 
-// MFMA block of the forward GEMM for one output tile: acc[j] = bias + sum_{Ti,r} W-frag * A[Ti][j][r]
-template <int W, int J>
-__device__ __forceinline__ void fwd_mma_tile(const float *img, int To, int p, int q,
-                                             const f32x4 (&A)[WidthCfg<W>::NT][J], f32x4 (&acc)[J])
+// Workgroup-level spin lock in LDS (lane 0 spins, the wave stays converged).  All eight waves of the
+// workgroup are resident and make progress independently, so the holder always gets to release.
+__device__ __forceinline__ void lds_lock(int *lk, int lane)
 {
-    typedef WidthCfg<W> C;
-#pragma unroll
-    for (int j = 0; j < J; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    acc[0] = *(const f32x4 *)&img[C::O_BIAS + 16 * To + 4 * q];
-#pragma unroll
-    for (int Ti = 0; Ti < C::NT; ++Ti) {
-        // A fragment: lane (m = p, q) holds W[16To + m][16Ti + 4q + r], r = 0..3
-        const f32x4 wf = *(const f32x4 *)&img[(16 * To + p) * C::S + 16 * Ti + 4 * q];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (16 * Ti + r < W) {     // compile-time: k-steps that only hit padding are dropped
-#pragma unroll
-                for (int j = 0; j < J; ++j) acc[j] = mfma4(wf[r], A[Ti][j][r], acc[j]);
-            }
-        }
+    for (;;) {
+        int old = 1;
+        if (lane == 0) old = atomicCAS(lk, 0, 1);
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == 0) break;
+        __builtin_amdgcn_s_sleep(2);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_unlock(int *lk, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(lk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 template <int EQ, int W, int MODE>
@@ -176,7 +239,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     constexpr int NT = C::NT, R = C::R, RR = C::RR, NM = C::NM, S = C::S;
     constexpr bool TAIL = C::TAIL;
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
-    constexpr int TILE = 256;                      // floats of one 16x16 stash/stage image
+    constexpr int TILE = 256;                      // floats of one 16x16 stash image
     constexpr int ZY = NT * J * TILE;              // main z (or y) images of one hidden layer
     constexpr int TS = ((RR * J * 16 + 63) / 64) * 64;  // tail z (or y) of one hidden layer: [e][k][p]
     constexpr int LAYER_STASH = 2 * ZY + 2 * TS;   // z main | y main | z tail | y tail
@@ -189,11 +252,13 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     const int nf = (EQ == EQ_NONE) ? nout : (EQ == EQ_GNSS ? 2 : 1);
     const int P = d.P;
     const int tid = threadIdx.x;
+    const bool rt_false = d.P < 0;   // never true; only the ablation builds read it
+    (void)rt_false;
 
     // ---- stage the weights in LDS (zero padded) ----
     for (int i = tid; i < L.zero_end; i += MFMA_BLOCK) lds[i] = 0.0f;
     if (MODE != MODE_FWD)
-        for (int i = tid; i < P + 2; i += MFMA_BLOCK) lds[L.gacc + i] = 0.0f;
+        for (int i = L.gs + tid; i < L.stage; i += MFMA_BLOCK) lds[i] = 0.0f;   // gs, images, locks
     __syncthreads();
     for (int l = 1; l <= n_lin - 2; ++l) {
         const float *Wg = a.theta + d.woff[l];
@@ -230,180 +295,234 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     }
     __syncthreads();
 
-    // wave id through readfirstlane: makes every per-wave base pointer provably wave-uniform, so the
-    // stash/stage accesses use scalar-base + lane-offset addressing instead of per-lane 64-bit pointers
-    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane & 15, q = lane >> 4;
+    // wave id through readfirstlane: makes every per-wave base provably wave-uniform
+    const int lane0 = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long wave_g = (long long)blockIdx.x * MFMA_WAVES + wv;
     const long long nwaves = (long long)gridDim.x * MFMA_WAVES;
     const long long ntiles = (a.n + 15) / 16;
     float *const st = stash + wave_g * (long long)(NH * LAYER_STASH);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(st, 0, NH * LAYER_STASH * 4, 0x00020000);
-    float *const stage = lds + L.stage + wv * NT * TILE;
-    float *const gacc = lds + L.gacc;
+    float *const stage = lds + L.stage + wv * NT * STAGE_TILE;
+    float *const gs = lds + L.gs;
     const float *const io = lds + L.io;
-    const int nat = p * 16 + 4 * q;               // this lane's f32x4 slot inside a [point][neuron] image
-    const int vnat = nat * 4, vlane = lane * 4, vp = p * 4;   // per-lane byte offsets for the stash buffer ops
+    // compact gradient block of Linear layer l < n_lin-1: bias first, then (hidden layers) tail rows / cols
+    auto gblock = [&](int l) { return gs + (l == 0 ? 2 * W : L.gs_hid + (l - 1) * L.gs_hid_stride); };
+    // per-lane byte offsets into the stash:
+    // Lane-derived indices and per-lane byte offsets into the stash.  They are re-derived from an opaque
+    // copy of the lane id at the start of every phase (PINN_REFRESH): left alone, the compiler hoists a
+    // few dozen loop-invariant per-lane addresses out of the tile loop, spills them, and every reload
+    // then waits (vmcnt) behind the stash stores in flight.
+    int lane, p, q;
+    int vnat;   // b128 slot of a [point][neuron] image (z) = transposed b128 slot of a [neuron][point] image (y)
+    int vyn;    // dword slot of neuron 4q (+r: add 16 floats) in a [neuron][point] image
+    int vp;
+#define PINN_REFRESH() do { lane = lane0; asm volatile("" : "+v"(lane)); p = lane & 15; q = lane >> 4; \
+        vnat = (p * 16 + 4 * q) * 4; vyn = (q * 64 + p) * 4; vp = p * 4; } while (0)
+    PINN_REFRESH();
     float lsum[MAXOUT] = {0.0f, 0.0f};
 
-    const float sx = 2.0f / (d.ubx - d.lbx), stt = 2.0f / (d.ubt - d.lbt);
+    // wave-uniform: keep them in SGPRs
+    const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f / (d.ubx - d.lbx))));
+    const float stt = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f / (d.ubt - d.lbt))));
+    float *const xtp = lds + L.xt + wv * 128;
 
     for (long long tile = wave_g; tile < ntiles; tile += nwaves) {
+        PINN_REFRESH();
         const long long pt = tile * 16 + p;
         const bool valid = pt < a.n;
         const long long pc = valid ? pt : a.n - 1;
         const float xv = a.x[pc * a.stride], tv = a.t[pc * a.stride];
-        const float hx = 2.0f * (xv - d.lbx) / (d.ubx - d.lbx) - 1.0f;
-        const float ht = 2.0f * (tv - d.lbt) / (d.ubt - d.lbt) - 1.0f;
+        // scaled coordinates: needed by the first layer now and again at the very end of the reverse
+        // sweep; in between they are parked in LDS (PINN_XT_PARK / PINN_XT_FETCH) instead of being
+        // spilled to scratch by the register allocator
+        float hx = 2.0f * (xv - d.lbx) / (d.ubx - d.lbx) - 1.0f;
+        float ht = 2.0f * (tv - d.lbt) / (d.ubt - d.lbt) - 1.0f;
+#define PINN_XT_PARK() do { xtp[lane] = hx; xtp[64 + lane] = ht; } while (0)
+#define PINN_XT_FETCH() do { asm volatile("" ::: "memory"); hx = xtp[lane]; ht = xtp[64 + lane]; } while (0)
+        if (MODE != MODE_FWD) PINN_XT_PARK();
 
-        f32x4 A[NT][J];        // tanh outputs of the current hidden layer, tiled neurons
-        float At[RR][J];       // ... tail neurons (same value in all four lane quads)
+        // The one register-resident set: activations on the way up, adjoints on the way down.
+        f32x4 A[NT][J];
+        float At[RR][J];       // tail neurons (same value in all four lane quads)
 
-        // ---- first layer (2 -> W), VALU: z0 = wx*hx + wt*ht + b, z1 = wx*sx, zt0 = wt*st ----
+        // first-layer pre-activation jets (also recomputed in the reverse sweep: they are affine in (x,t),
+        // so they are never stashed).  Weights of tile T as three b128 LDS reads, then neuron r of them.
+        struct W0 { f32x4 wx, wt, b0; };
+        auto w0_tile = [&](int T) __attribute__((always_inline)) {
+            W0 w;
+            w.wx = *(const f32x4 *)&io[C::O_W0X + 16 * T + 4 * q];
+            w.wt = *(const f32x4 *)&io[C::O_W0T + 16 * T + 4 * q];
+            w.b0 = *(const f32x4 *)&io[C::O_B0 + 16 * T + 4 * q];
+            return w;
+        };
+        auto z0_main = [&](const W0 &w, int r, float (&z)[J]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int T = 0; T < NT; ++T) {
-            const f32x4 wx = *(const f32x4 *)&io[C::O_W0X + 16 * T + 4 * q];
-            const f32x4 wt = *(const f32x4 *)&io[C::O_W0T + 16 * T + 4 * q];
-            const f32x4 b0 = *(const f32x4 *)&io[C::O_B0 + 16 * T + 4 * q];
-            f32x4 zq[J];
+            for (int j = 0; j < J; ++j) z[j] = 0.0f;
+            z[0] = fmaf(w.wx[r], hx, fmaf(w.wt[r], ht, w.b0[r]));
+            if (K >= 1) z[K >= 1 ? 1 : 0] = w.wx[r] * sx;
+            if (KT >= 1) z[KT >= 1 ? K + 1 : 0] = w.wt[r] * stt;
+        };
+        auto z0_tail = [&](int e, float (&z)[J]) __attribute__((always_inline)) {
+            const float wx = io[C::O_W0TAIL + e], wt = io[C::O_W0TAIL + 4 + e], b0 = io[C::O_W0TAIL + 8 + e];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float z[J], y[J], w[K + 1];
+            for (int j = 0; j < J; ++j) z[j] = 0.0f;
+            z[0] = fmaf(wx, hx, fmaf(wt, ht, b0));
+            if (K >= 1) z[K >= 1 ? 1 : 0] = wx * sx;
+            if (KT >= 1) z[KT >= 1 ? K + 1 : 0] = wt * stt;
+        };
+
+        // ---- first layer (2 -> W), VALU ----
+        {
+            const bool keep_y = (MODE != MODE_FWD) && NH > 1;
 #pragma unroll
-                for (int j = 0; j < J; ++j) z[j] = 0.0f;
-                z[0] = fmaf(wx[r], hx, fmaf(wt[r], ht, b0[r]));
-                if (K >= 1) z[1] = wx[r] * sx;
-                if (KT >= 1) z[K + 1] = wt[r] * stt;
-                tanh_jet_fwd<K, KT>(z, y, w);
+            for (int T = 0; T < NT; ++T) {
+                const W0 w0 = w0_tile(T);
 #pragma unroll
-                for (int j = 0; j < J; ++j) { A[T][j][r] = y[j]; zq[j][r] = z[j]; }
-            }
-            if (MODE != MODE_FWD) {
+                for (int r = 0; r < 4; ++r) {
+                    float z[J], y[J], w[K + 1];
+                    z0_main(w0, r, z);
+                    tanh_jet_fwd<K, KT>(z, y, w);
 #pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    sb_store4(srs, vnat, (T * J + j) * TILE, zq[j]);
-                    sb_store4(srs, vnat, ZY + (T * J + j) * TILE, A[T][j]);
-                }
-            }
+                    for (int j = 0; j < J; ++j) pin(y[j]);
 #pragma unroll
-            for (int j = 0; j < J; ++j) park(A[T][j]);
-        }
+                    for (int j = 0; j < J; ++j) A[T][j][r] = y[j];
+                    if (keep_y) {
 #pragma unroll
-        for (int e = 0; e < RR; ++e)
-#pragma unroll
-            for (int j = 0; j < J; ++j) At[e][j] = 0.0f;
-        if (TAIL) {
-#pragma unroll
-            for (int e = 0; e < R; ++e) {
-                float z[J], w[K + 1];
-#pragma unroll
-                for (int j = 0; j < J; ++j) z[j] = 0.0f;
-                const float wx = io[C::O_W0TAIL + e], wt = io[C::O_W0TAIL + 4 + e], b0 = io[C::O_W0TAIL + 8 + e];
-                z[0] = fmaf(wx, hx, fmaf(wt, ht, b0));
-                if (K >= 1) z[1] = wx * sx;
-                if (KT >= 1) z[K + 1] = wt * stt;
-                tanh_jet_fwd<K, KT>(z, At[e], w);
-                if (MODE != MODE_FWD && q == 0) {
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, z[j]);
-                        sb_store1(srs, vp, 2 * ZY + TS + (e * J + j) * 16, At[e][j]);
+                        for (int j = 0; j < J; ++j) sb_store1(srs, vyn, ZY + (T * J + j) * TILE + r * 16, y[j]);
                     }
+                    PINN_SB();
                 }
             }
-        }
-
-        // ---- hidden -> hidden layers on the matrix cores ----
-        for (int l = 1; l <= n_lin - 2; ++l) {
-            const float *img = lds + L.hh + (l - 1) * C::HH;
-            const int zs = l * LAYER_STASH;   // stash offset (floats) of this layer
-            f32x4 B[NT][J];
-            float Bt[RR][J];
 #pragma unroll
             for (int e = 0; e < RR; ++e)
 #pragma unroll
-                for (int j = 0; j < J; ++j) Bt[e][j] = 0.0f;
-            // software pipeline: the MFMA block of output tile To+1 is issued before the VALU work
-            // (tail neurons, tanh jets) of tile To, so the matrix pipe runs under the vector work
-            f32x4 acc[2][J];
-            fwd_mma_tile<W, J>(img, 0, p, q, A, acc[0]);
+                for (int j = 0; j < J; ++j) At[e][j] = 0.0f;
             if (TAIL) {
-                // tail outputs: every lane sums over its 4*NT tiled inputs, then across the lane quads
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
                     float z[J], w[K + 1];
+                    z0_tail(e, z);
+                    tanh_jet_fwd<K, KT>(z, At[e], w);
+                    if (keep_y && q == 0) {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) z[j] = 0.0f;
-#pragma unroll
-                    for (int Ti = 0; Ti < NT; ++Ti) {
-                        const f32x4 wr = *(const f32x4 *)&img[C::O_WTR + e * NM + 16 * Ti + 4 * q];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-#pragma unroll
-                            for (int j = 0; j < J; ++j) z[j] = fmaf(wr[r], A[Ti][j][r], z[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < J; ++j) z[j] = quad_rows_sum(z[j]);
-                    z[0] += img[C::O_BT + e];
-#pragma unroll
-                    for (int e2 = 0; e2 < R; ++e2) {
-                        const float wtt = img[C::O_WTT + e * 4 + e2];
-#pragma unroll
-                        for (int j = 0; j < J; ++j) z[j] = fmaf(wtt, At[e2][j], z[j]);
-                    }
-                    tanh_jet_fwd<K, KT>(z, Bt[e], w);
-                    if (MODE != MODE_FWD && q == 0) {
-#pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            sb_store1(srs, vp, zs + 2 * ZY + (e * J + j) * 16, z[j]);
-                            sb_store1(srs, vp, zs + 2 * ZY + TS + (e * J + j) * 16, Bt[e][j]);
-                        }
+                        for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + TS + (e * J + j) * 16, At[e][j]);
                     }
                 }
             }
+        }
+
+
+#if PINN_CUT == 1
+        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
+          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
+#endif
+        // ---- hidden -> hidden layers on the matrix cores, one jet component at a time, in place ----
+        for (int l = 1; l <= n_lin - 2; ++l) {
+            PINN_REFRESH();
+            const float *img = lds + L.hh + (l - 1) * C::HH;
+            const int zs = l * LAYER_STASH;   // stash offset (floats) of this layer
+            const bool keep_y = (MODE != MODE_FWD) && l < NH - 1;
+            float zt[RR][J];
 #pragma unroll
-            for (int To = 0; To < NT; ++To) {
-                if (To + 1 < NT) fwd_mma_tile<W, J>(img, To + 1, p, q, A, acc[(To + 1) & 1]);
-                f32x4 (&ac)[J] = acc[To & 1];
+            for (int e = 0; e < RR; ++e)
+#pragma unroll
+                for (int j = 0; j < J; ++j) zt[e][j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                f32x4 acc[NT];
+#pragma unroll
+                for (int To = 0; To < NT; ++To) {
+                    acc[To] = (j == 0) ? *(const f32x4 *)&img[C::O_BIAS + 16 * To + 4 * q] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                    if (TAIL) {
+                        // tail inputs into the tiled outputs: part of the accumulator's initial value
+#pragma unroll
+                        for (int e = 0; e < R; ++e) {
+                            const f32x4 wc = *(const f32x4 *)&img[C::O_WTC + e * NM + 16 * To + 4 * q];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[To][r] = fmaf(wc[r], At[e][j], acc[To][r]);
+                        }
+                    }
+#pragma unroll
+                    for (int Ti = 0; Ti < NT; ++Ti) {
+                        // A fragment: lane (m = p, q) holds W[16To + m][16Ti + 4q + r], r = 0..3
+                        const f32x4 wf = *(const f32x4 *)&img[(16 * To + p) * S + 16 * Ti + 4 * q];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * Ti + r < W) acc[To] = mfma4(wf[r], A[Ti][j][r], acc[To]);
+                    }
+                    PINN_SB();
+                }
+                PINN_SB();
                 if (TAIL) {
+                    // tail outputs: every lane sums over its 4*NT tiled inputs, then across the lane quads
 #pragma unroll
                     for (int e = 0; e < R; ++e) {
-                        const f32x4 wc = *(const f32x4 *)&img[C::O_WTC + e * NM + 16 * To + 4 * q];
+                        float s = 0.0f;
 #pragma unroll
-                        for (int j = 0; j < J; ++j) ac[j] += wc * At[e][j];
+                        for (int Ti = 0; Ti < NT; ++Ti) {
+                            const f32x4 wr = *(const f32x4 *)&img[C::O_WTR + e * NM + 16 * Ti + 4 * q];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s = fmaf(wr[r], A[Ti][j][r], s);
+                        }
+                        s = quad_rows_sum(s);
+                        if (j == 0) s += img[C::O_BT + e];
+#pragma unroll
+                        for (int e2 = 0; e2 < R; ++e2) s = fmaf(img[C::O_WTT + e * 4 + e2], At[e2][j], s);
+                        zt[e][j] = s;
+                        PINN_SB();
                     }
                 }
-                if (MODE != MODE_FWD) {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) sb_store4(srs, vnat, zs + (To * J + j) * TILE, ac[j]);
-                }
+                for (int To = 0; To < NT; ++To) A[To][j] = acc[To];
+                PINN_JB();
+            }
+            // A = z of this layer: stash it and apply tanh in place, neuron by neuron
+            PINN_REFRESH();
+#pragma unroll
+            for (int To = 0; To < NT; ++To)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float z[J], y[J], w[K + 1];
 #pragma unroll
-                    for (int j = 0; j < J; ++j) z[j] = ac[j][r];
+                    for (int j = 0; j < J; ++j) z[j] = A[To][j][r];
+                    if (MODE != MODE_FWD) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) sb_store1(srs, vyn, zs + (To * J + j) * TILE + r * 16, z[j]);
+                    }
                     tanh_jet_fwd<K, KT>(z, y, w);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) B[To][j][r] = y[j];
-                }
-                if (MODE != MODE_FWD) {
+                    for (int j = 0; j < J; ++j) pin(y[j]);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) sb_store4(srs, vnat, zs + ZY + (To * J + j) * TILE, B[To][j]);
-                }
+                    for (int j = 0; j < J; ++j) A[To][j][r] = y[j];
+                    if (keep_y) {
 #pragma unroll
-                for (int j = 0; j < J; ++j) park(B[To][j]);
+                        for (int j = 0; j < J; ++j) sb_store1(srs, vyn, zs + ZY + (To * J + j) * TILE + r * 16, y[j]);
+                    }
+                    PINN_SB();
+                }
+            if (TAIL) {
+#pragma unroll
+                for (int e = 0; e < R; ++e) {
+                    float w[K + 1];
+                    tanh_jet_fwd<K, KT>(zt[e], At[e], w);
+                    if (MODE != MODE_FWD && q == 0) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            sb_store1(srs, vp, zs + 2 * ZY + (e * J + j) * 16, zt[e][j]);
+                            if (keep_y) sb_store1(srs, vp, zs + 2 * ZY + TS + (e * J + j) * 16, At[e][j]);
+                        }
+                    }
+                }
             }
-#pragma unroll
-            for (int T = 0; T < NT; ++T)
-#pragma unroll
-                for (int j = 0; j < J; ++j) A[T][j] = B[T][j];
-#pragma unroll
-            for (int e = 0; e < RR; ++e)
-#pragma unroll
-                for (int j = 0; j < J; ++j) At[e][j] = Bt[e][j];
         }
 
+
+#if PINN_CUT == 2
+        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
+          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
+#endif
         // ---- output layer (W -> nout), VALU + cross-quad reduction ----
+        PINN_REFRESH();
         float D[MAXOUT][J], Tt[MAXOUT][J];
 #pragma unroll
         for (int o = 0; o < MAXOUT; ++o) {
@@ -464,184 +583,135 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                 fb[c] = valid ? a.gbar[pt * nf + c] : 0.0f;
             }
         }
-        float Db[MAXOUT][J], Tb[MAXOUT][J];
+        float ub[MAXOUT][J];
+        {
+            float Db[MAXOUT][J], Tb[MAXOUT][J];
+#pragma unroll
+            for (int o = 0; o < MAXOUT; ++o)
+#pragma unroll
+                for (int j = 0; j < J; ++j) { Db[o][j] = 0.0f; Tb[o][j] = 0.0f; }
+            Residual<EQ>::adj(D, Tt, d.coef, nout, fb, Db, Tb);
+#pragma unroll
+            for (int o = 0; o < MAXOUT; ++o) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) ub[o][j] = 0.0f;
+#pragma unroll
+                for (int k = 0; k <= K; ++k) ub[o][k] = factorial(k) * Db[o][k];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) ub[o][K + 1 + k] = factorial(k) * Tb[o][k];
+            }
+        }
+
+
+#if PINN_CUT == 3
+        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
+          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
+#endif
+        // ---- output layer: bias gradient ----
+        PINN_REFRESH();
 #pragma unroll
         for (int o = 0; o < MAXOUT; ++o)
-#pragma unroll
-            for (int j = 0; j < J; ++j) { Db[o][j] = 0.0f; Tb[o][j] = 0.0f; }
-        Residual<EQ>::adj(D, Tt, d.coef, nout, fb, Db, Tb);
-        float ub[MAXOUT][J];
-#pragma unroll
-        for (int o = 0; o < MAXOUT; ++o) {
-#pragma unroll
-            for (int k = 0; k <= K; ++k) ub[o][k] = factorial(k) * Db[o][k];
-#pragma unroll
-            for (int k = 0; k < KT; ++k) ub[o][K + 1 + k] = factorial(k) * Tb[o][k];
-        }
-
-        // ---- output layer reverse: its weight gradient and the adjoint of the last tanh outputs ----
-        f32x4 G[NT][J];
-        float Gt[RR][J];
-#pragma unroll
-        for (int T = 0; T < NT; ++T)
-#pragma unroll
-            for (int j = 0; j < J; ++j) G[T][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int e = 0; e < RR; ++e)
-#pragma unroll
-            for (int j = 0; j < J; ++j) Gt[e][j] = 0.0f;
-#pragma unroll
-        for (int o = 0; o < MAXOUT; ++o) {
             if (o < nout) {
-                float *gw = gacc + d.woff[n_lin - 1] + o * W;
                 const float bs = row_sum16(ub[o][0]);
-                if (lane == 0) atomicAdd(&gacc[d.boff[n_lin - 1] + o], bs);
-#pragma unroll
-                for (int T = 0; T < NT; ++T) {
-                    const f32x4 wo = *(const f32x4 *)&io[C::O_WOUT + o * NM + 16 * T + 4 * q];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = 0.0f;
-#pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            v = fmaf(ub[o][j], A[T][j][r], v);
-                            G[T][j][r] = fmaf(wo[r], ub[o][j], G[T][j][r]);
-                        }
-                        v = row_sum16(v);
-                        const int n = 16 * T + 4 * q + r;
-                        if (p == 0 && n < W) atomicAdd(&gw[n], v);
-                    }
-                }
-                if (TAIL) {
-#pragma unroll
-                    for (int e = 0; e < R; ++e) {
-                        const float wo = io[C::O_WOUTT + o * 4 + e];
-                        float v = 0.0f;
-#pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            v = fmaf(ub[o][j], At[e][j], v);
-                            Gt[e][j] = fmaf(wo, ub[o][j], Gt[e][j]);
-                        }
-                        v = row_sum16(v);
-                        if (lane == 0) atomicAdd(&gw[NM + e], v);
-                    }
-                }
+                if (lane == 0) PINN_ADD_S(&gs[L.gs_out + nout * W + o], bs);
             }
-        }
 
-#pragma unroll
-        for (int T = 0; T < NT; ++T)
-#pragma unroll
-            for (int j = 0; j < J; ++j) park(G[T][j]);
-
-        // ---- reverse sweep over the tanh layers hl = NH-1 .. 0 ----
-        // on entry G/Gt = adjoint of y_hl; after the tanh reverse they are the adjoint of z_hl.
-        // Ct carries the tail rows of Zb of the layer above (hl+1) whose weight gradient against the
-        // tiled y_hl is formed here, where y_hl is loaded anyway.
-        float Ct[RR][J];
-#pragma unroll
-        for (int e = 0; e < RR; ++e)
-#pragma unroll
-            for (int j = 0; j < J; ++j) Ct[e][j] = 0.0f;
-
-        f32x4 zq[2][J], yq[2][J];
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-            zq[0][j] = sb_load4(srs, vnat, (NH - 1) * LAYER_STASH + (0 * J + j) * TILE);
-            yq[0][j] = sb_load4(srs, vnat, (NH - 1) * LAYER_STASH + ZY + (0 * J + j) * TILE);
-        }
-        for (int hl = NH - 1; hl >= 0; --hl) {
+        // ---- top tanh layer (NH-1): y is still in registers, its adjoint is the outer product
+        //      Wout^T ub, and the output layer's weight gradient is formed on the way.  A/At: y -> Zb. ----
+        {
+            const int hl = NH - 1;
             const int zs = hl * LAYER_STASH;
-            const bool above = hl < NH - 1;     // Linear layer hl+1 (hidden->hidden) sits above
-            float *gw_above = gacc + d.woff[above ? hl + 1 : 0];
-            // tails first (their stash rows are tiny broadcast loads)
+            float *gbias = gblock(hl);
+            if (hl == 0) PINN_XT_FETCH();
             if (TAIL) {
-                float yt[RR][J];
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
-                    float z[J], w[K + 1], zb[J];
+                    float z[J], w[K + 1], yb[J], zb[J];
+                    if (hl > 0) {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        z[j] = sb_load1(srs, vp, zs + 2 * ZY + (e * J + j) * 16);
-                        yt[e][j] = sb_load1(srs, vp, zs + 2 * ZY + TS + (e * J + j) * 16);
+                        for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vp, zs + 2 * ZY + (e * J + j) * 16);
+                    } else {
+                        z0_tail(e, z);
                     }
-                    w_from_y<K>(yt[e], w);
-                    tanh_jet_bwd<K, KT>(z, yt[e], w, Gt[e], zb);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) Gt[e][j] = zb[j];
-                    const float bs = row_sum16(zb[0]);
-                    if (lane == 0) atomicAdd(&gacc[d.boff[hl] + NM + e], bs);
-                }
-                if (above) {
-                    // tail x tail block of Wb_{hl+1}
+                    for (int j = 0; j < J; ++j) yb[j] = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < R; ++e)
-#pragma unroll
-                        for (int e2 = 0; e2 < R; ++e2) {
+                    for (int o = 0; o < MAXOUT; ++o)
+                        if (o < nout) {
+                            const float wo = io[C::O_WOUTT + o * 4 + e];
                             float v = 0.0f;
 #pragma unroll
-                            for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], yt[e2][j], v);
+                            for (int j = 0; j < J; ++j) {
+                                v = fmaf(ub[o][j], At[e][j], v);
+                                yb[j] = fmaf(wo, ub[o][j], yb[j]);
+                            }
                             v = row_sum16(v);
-                            if (lane == 0) atomicAdd(&gw_above[(NM + e) * W + NM + e2], v);
+                            if (lane == 0) PINN_ADD_S(&gs[L.gs_out + o * W + NM + e], v);
                         }
+                    w_from_y<K>(At[e], w);
+                    tanh_jet_bwd<K, KT>(z, At[e], w, yb, zb);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) At[e][j] = zb[j];
+                    const float bs = row_sum16(zb[0]);
+                    if (lane == 0) PINN_ADD_S(&gbias[NM + e], bs);
                 }
             }
-            // tiled neurons: z/y tiles of this layer come back from the stash as f32x4 rows; tile T+1 is
-            // in flight while tile T is processed, and tile 0 of the NEXT layer down is requested before
-            // the MFMA phases below so that its latency hides under them.
 #pragma unroll
             for (int T = 0; T < NT; ++T) {
-                if (T + 1 < NT) {
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        zq[(T + 1) & 1][j] = sb_load4(srs, vnat, zs + ((T + 1) * J + j) * TILE);
-                        yq[(T + 1) & 1][j] = sb_load4(srs, vnat, zs + ZY + ((T + 1) * J + j) * TILE);
-                    }
-                }
+                W0 w0;
+                if (hl == 0) w0 = w0_tile(T);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float z[J], y[J], w[K + 1], yb[J], zb[J];
+                    const int n = 16 * T + 4 * q + r;
+                    if (hl > 0) {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) { z[j] = zq[T & 1][j][r]; y[j] = yq[T & 1][j][r]; yb[j] = G[T][j][r]; }
+                        for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vyn, zs + (T * J + j) * TILE + r * 16);
+                    } else {
+                        z0_main(w0, r, z);
+                    }
+#pragma unroll
+                    for (int j = 0; j < J; ++j) { y[j] = A[T][j][r]; yb[j] = 0.0f; }
+#pragma unroll
+                    for (int o = 0; o < MAXOUT; ++o)
+                        if (o < nout) {
+                            const float wo = io[C::O_WOUT + o * NM + n];
+                            float v = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) {
+                                v = fmaf(ub[o][j], y[j], v);
+                                yb[j] = fmaf(wo, ub[o][j], yb[j]);
+                            }
+                            v = row_sum16(v);
+                            if (p == 0 && n < W) PINN_ADD_S(&gs[L.gs_out + o * W + n], v);
+                        }
                     w_from_y<K>(y, w);
                     tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) G[T][j][r] = zb[j];
-                    const int n = 16 * T + 4 * q + r;
-                    // bias gradient of the layer that produced z_hl
+                    for (int j = 0; j < J; ++j) pin(zb[j]);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) A[T][j][r] = zb[j];
                     const float bs = row_sum16(zb[0]);
-                    if (p == 0 && n < W) atomicAdd(&gacc[d.boff[hl] + n], bs);
-                    if (TAIL && above) {
-                        // tail rows of Wb_{hl+1} against this tile of y_hl
-#pragma unroll
-                        for (int e = 0; e < R; ++e) {
-                            float v = 0.0f;
-#pragma unroll
-                            for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], y[j], v);
-                            v = row_sum16(v);
-                            if (p == 0) atomicAdd(&gw_above[(NM + e) * W + n], v);
-                        }
-                    }
+                    if (p == 0 && n < W) PINN_ADD_S(&gbias[n], bs);
                     PINN_SB();
                 }
-#pragma unroll
-                for (int j = 0; j < J; ++j) park(G[T][j]);
             }
-            if (hl > 0) {
-                const int zn = (hl - 1) * LAYER_STASH;
-#pragma unroll
-                for (int j = 0; j < J; ++j) {
-                    zq[0][j] = sb_load4(srs, vnat, zn + (0 * J + j) * TILE);
-                    yq[0][j] = sb_load4(srs, vnat, zn + ZY + (0 * J + j) * TILE);
-                }
-            }
-            if (hl == 0) break;
+        }
 
-            // Linear layer l = hl maps y_{hl-1} -> z_hl
-            const int l = hl;
+
+#if PINN_CUT == 4
+        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
+          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
+#endif
+        // ---- Linear layers l = NH-1 .. 1 (hidden -> hidden), each followed by the tanh layer below it ----
+        for (int l = NH - 1; l >= 1; --l) {
+            PINN_REFRESH();
+            // on entry A/At = Zb (adjoint of z_l);  Linear layer l maps y_{l-1} -> z_l
             const float *img = lds + L.hh + (l - 1) * C::HH;
-            const int yprev = (hl - 1) * LAYER_STASH + ZY;
-            float *gw = gacc + d.woff[l];
+            const int yprev = (l - 1) * LAYER_STASH + ZY;
+            float *gtc = gblock(l) + W + R * W;                                   // tail columns of Wb_l: [o][e]
+            float *gtr = gblock(l) + W;                                           // tail rows of Wb_l: [e][i]
+            float *wim = lds + L.wimg + (l - 1) * (NT * NT * TILE);              // main block of Wb_l
 
             // Phase A: Wb[o][i] += sum_{p,k} Zb_k[o][p] * Y_k[i][p]   (reduction over points)
             {
@@ -650,191 +720,297 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                 for (int To = 0; To < NT; ++To)
 #pragma unroll
                     for (int Ti = 0; Ti < NT; ++Ti) wacc[To][Ti] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-                float bop[2][NT][4];
-#pragma unroll
-                for (int Ti = 0; Ti < NT; ++Ti)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) bop[0][Ti][s] = sb_load1(srs, vlane, yprev + (Ti * J + 0) * TILE + 64 * s);
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                    if (j + 1 < J) {
+                    // B operand: lane (n = p, kk = q) gets y[16Ti + n][points 4kk .. 4kk+3]
+                    f32x4 bop[NT];
 #pragma unroll
-                        for (int Ti = 0; Ti < NT; ++Ti)
+                    for (int Ti = 0; Ti < NT; ++Ti) bop[Ti] = sb_load4(srs, vnat, yprev + (Ti * J + j) * TILE);
+                    // A operand: Zb through the staging image [point][neuron] -> lane (m = p, kk = q) reads
+                    // Zb[16To + m][point 4kk + s]
 #pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                bop[(j + 1) & 1][Ti][s] = sb_load1(srs, vlane, yprev + (Ti * J + j + 1) * TILE + 64 * s);
-                    }
-#pragma unroll
-                    for (int To = 0; To < NT; ++To) *(f32x4 *)&stage[To * TILE + nat] = G[To][j];
+                    for (int To = 0; To < NT; ++To) *(f32x4 *)&stage[To * STAGE_TILE + p * STAGE_ROW + 4 * q] = A[To][j];
                     PINN_LDS_FENCE();
                     float aop[NT][4];
 #pragma unroll
                     for (int To = 0; To < NT; ++To)
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) aop[To][s] = stage[To * TILE + 64 * s + lane];
+                        for (int s = 0; s < 4; ++s) aop[To][s] = stage[To * STAGE_TILE + (4 * q + s) * STAGE_ROW + p];
                     PINN_LDS_FENCE();
 #pragma unroll
                     for (int To = 0; To < NT; ++To)
 #pragma unroll
                         for (int Ti = 0; Ti < NT; ++Ti)
 #pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                wacc[To][Ti] = mfma4(aop[To][s], bop[j & 1][Ti][s], wacc[To][Ti]);
-                    PINN_SB();
+                            for (int s = 0; s < 4; ++s) wacc[To][Ti] = mfma4(aop[To][s], bop[Ti][s], wacc[To][Ti]);
+                    PINN_JB();
                 }
-                // accumulator (To,Ti): lane (i = p, q) holds Wb[16To + 4q + r][16Ti + p]
-                float *gl = gw + 4 * q * W + p;
-#pragma unroll
-                for (int To = 0; To < NT; ++To)
-#pragma unroll
-                    for (int Ti = 0; Ti < NT; ++Ti)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int o = 16 * To + 4 * q + r, i = 16 * Ti + p;
-                            if (TAIL || (o < W && i < W)) atomicAdd(&gl[(16 * To + r) * W + 16 * Ti], wacc[To][Ti][r]);
-                        }
-                if (TAIL) {
-                    // tiled rows x tail columns: Wb[o][NM+e] = sum_{p,k} Zb_k[o][p] * ytail_k[e][p]
-                    float yp[RR][J];
-#pragma unroll
-                    for (int e = 0; e < R; ++e)
-#pragma unroll
-                        for (int j = 0; j < J; ++j) yp[e][j] = sb_load1(srs, vp, yprev + ZY + TS + (e * J + j) * 16);
+                // accumulator (To,Ti): lane (i = p, q) register r holds Wb[16To + 4q + r][16Ti + p]
+                if (!PINN_ABL_WACC || rt_false) {
+                    int *lk = (int *)(lds + L.locks) + (l - 1);
+                    lds_lock(lk, lane);
 #pragma unroll
                     for (int To = 0; To < NT; ++To)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
+                        for (int Ti = 0; Ti < NT; ++Ti) {
+                            f32x4 *dst = (f32x4 *)&wim[(To * NT + Ti) * TILE + lane * 4];
+                            *dst = *dst + wacc[To][Ti];
+                        }
+                    lds_unlock(lk, lane);
+                }
+                PINN_SB();
+                if (TAIL) {
+                    // tiled rows x tail columns: Wb[o][NM+e] = sum_{p,k} Zb_k[o][p] * ytail_k[e][p]
 #pragma unroll
-                            for (int e = 0; e < R; ++e) {
+                    for (int e = 0; e < R; ++e) {
+                        float yp[J];
+#pragma unroll
+                        for (int j = 0; j < J; ++j) yp[j] = sb_load1(srs, vp, yprev + ZY + TS + (e * J + j) * 16);
+#pragma unroll
+                        for (int To = 0; To < NT; ++To)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
                                 float v = 0.0f;
 #pragma unroll
-                                for (int j = 0; j < J; ++j) v = fmaf(G[To][j][r], yp[e][j], v);
+                                for (int j = 0; j < J; ++j) v = fmaf(A[To][j][r], yp[j], v);
                                 v = row_sum16(v);
-                                if (p == 0) atomicAdd(&gw[(16 * To + 4 * q + r) * W + NM + e], v);
+                                if (p == 0) PINN_ADD_S(&gtc[(16 * To + 4 * q + r) * R + e], v);
                             }
+                    }
                 }
             }
+            PINN_SB();
+            PINN_REFRESH();
 
-            // Phase B: Yb^T[i][p] = sum_o W[o][i] Zb^T[o][p]
-            f32x4 H[NT][J];
-            float Ht[RR][J];
+            // Phase B: Yb^T[i][p] = sum_o W[o][i] Zb^T[o][p], one jet component at a time, in place.
+            // Ct keeps the tail rows of Zb: their weight gradient against the tiled y_{l-1} is formed
+            // below, where y_{l-1} is loaded anyway.
+            float Ct[RR][J];
+            {
+                float Ht[RR][J];
 #pragma unroll
-            for (int e = 0; e < RR; ++e)
+                for (int e = 0; e < RR; ++e)
 #pragma unroll
-                for (int j = 0; j < J; ++j) Ht[e][j] = 0.0f;
-            if (TAIL) {
-                // adjoint of the tail inputs: sum over tiled outputs (cross-quad) + tail outputs
+                    for (int j = 0; j < J; ++j) Ht[e][j] = 0.0f;
 #pragma unroll
-                for (int e2 = 0; e2 < R; ++e2) {
-                    float h[J];
+                for (int j = 0; j < J; ++j) {
+                    f32x4 acc[NT];
 #pragma unroll
-                    for (int j = 0; j < J; ++j) h[j] = 0.0f;
+                    for (int Ti = 0; Ti < NT; ++Ti) {
+                        acc[Ti] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                        if (TAIL) {
+                            // tail outputs' contribution: part of the accumulator's initial value
 #pragma unroll
-                    for (int To = 0; To < NT; ++To) {
-                        const f32x4 wc = *(const f32x4 *)&img[C::O_WTC + e2 * NM + 16 * To + 4 * q];
+                            for (int e = 0; e < R; ++e) {
+                                const f32x4 wr = *(const f32x4 *)&img[C::O_WTR + e * NM + 16 * Ti + 4 * q];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
+                                for (int r = 0; r < 4; ++r) acc[Ti][r] = fmaf(wr[r], At[e][j], acc[Ti][r]);
+                            }
+                        }
 #pragma unroll
-                            for (int j = 0; j < J; ++j) h[j] = fmaf(wc[r], G[To][j][r], h[j]);
+                        for (int To = 0; To < NT; ++To)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (16 * To + r < W) {
+                                    // A fragment: lane (m = p, q) holds W[16To + 4q + r][16Ti + m]
+                                    const float wf = img[(16 * To + 4 * q + r) * S + 16 * Ti + p];
+                                    acc[Ti] = mfma4(wf, A[To][j][r], acc[Ti]);
+                                }
+                        PINN_SB();
                     }
+                    PINN_SB();
+                    if (TAIL) {
+                        // adjoint of the tail inputs: sum over tiled outputs (cross-quad) + tail outputs
 #pragma unroll
-                    for (int j = 0; j < J; ++j) h[j] = quad_rows_sum(h[j]);
+                        for (int e2 = 0; e2 < R; ++e2) {
+                            float h = 0.0f;
 #pragma unroll
-                    for (int e = 0; e < R; ++e) {
-                        const float wtt = img[C::O_WTT + e * 4 + e2];
+                            for (int To = 0; To < NT; ++To) {
+                                const f32x4 wc = *(const f32x4 *)&img[C::O_WTC + e2 * NM + 16 * To + 4 * q];
 #pragma unroll
-                        for (int j = 0; j < J; ++j) h[j] = fmaf(wtt, Gt[e][j], h[j]);
-                    }
+                                for (int r = 0; r < 4; ++r) h = fmaf(wc[r], A[To][j][r], h);
+                            }
+                            h = quad_rows_sum(h);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) Ht[e2][j] = h[j];
-                }
-            }
-#pragma unroll
-            for (int Ti = 0; Ti < NT; ++Ti) {
-                f32x4 acc[J];
-#pragma unroll
-                for (int j = 0; j < J; ++j) acc[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int To = 0; To < NT; ++To) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (16 * To + r < W) {
-                            // A fragment: lane (m = p, q) holds W[16To + 4q + r][16Ti + m]
-                            const float wf = img[(16 * To + 4 * q + r) * S + 16 * Ti + p];
-#pragma unroll
-                            for (int j = 0; j < J; ++j) acc[j] = mfma4(wf, G[To][j][r], acc[j]);
+                            for (int e = 0; e < R; ++e) h = fmaf(img[C::O_WTT + e * 4 + e2], At[e][j], h);
+                            Ht[e2][j] = h;
+                            PINN_SB();
                         }
                     }
-                }
-                if (TAIL) {
 #pragma unroll
-                    for (int e = 0; e < R; ++e) {
-                        const f32x4 wr = *(const f32x4 *)&img[C::O_WTR + e * NM + 16 * Ti + 4 * q];
-#pragma unroll
-                        for (int j = 0; j < J; ++j) acc[j] += wr * Gt[e][j];
-                    }
+                    for (int Ti = 0; Ti < NT; ++Ti) A[Ti][j] = acc[Ti];
+                    PINN_JB();
                 }
 #pragma unroll
-                for (int j = 0; j < J; ++j) { H[Ti][j] = acc[j]; park(H[Ti][j]); }
-                PINN_SB();
+                for (int e = 0; e < RR; ++e)
+#pragma unroll
+                    for (int j = 0; j < J; ++j) { Ct[e][j] = At[e][j]; At[e][j] = Ht[e][j]; }
             }
+
+            // tanh layer hl = l-1: A/At = adjoint of y_hl -> adjoint of z_hl, in place
+            PINN_REFRESH();
+            const int hl = l - 1;
+            const int zs = hl * LAYER_STASH;
+            float *gbias = gblock(hl);
+            if (hl == 0) PINN_XT_FETCH();
 #pragma unroll
-            for (int T = 0; T < NT; ++T)
+            for (int T = 0; T < NT; ++T) {
+                W0 w0;
+                if (hl == 0) w0 = w0_tile(T);
 #pragma unroll
-                for (int j = 0; j < J; ++j) G[T][j] = H[T][j];
+                for (int r = 0; r < 4; ++r) {
+                    float z[J], y[J], w[K + 1], yb[J], zb[J];
+                    const int n = 16 * T + 4 * q + r;
+                    if (hl > 0) {
 #pragma unroll
-            for (int e = 0; e < RR; ++e)
+                        for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vyn, zs + (T * J + j) * TILE + r * 16);
+                    } else {
+                        z0_main(w0, r, z);
+                    }
 #pragma unroll
-                for (int j = 0; j < J; ++j) { Ct[e][j] = Gt[e][j]; Gt[e][j] = Ht[e][j]; }
+                    for (int j = 0; j < J; ++j) {
+                        y[j] = sb_load1(srs, vyn, zs + ZY + (T * J + j) * TILE + r * 16);
+                        yb[j] = A[T][j][r];
+                    }
+                    if (TAIL) {
+                        // tail rows of Wb_l against this neuron of y_hl
+#pragma unroll
+                        for (int e = 0; e < R; ++e) {
+                            float v = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], y[j], v);
+                            v = row_sum16(v);
+                            if (p == 0) PINN_ADD_S(&gtr[e * W + n], v);
+                        }
+                    }
+                    w_from_y<K>(y, w);
+                    tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) pin(zb[j]);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) A[T][j][r] = zb[j];
+                    const float bs = row_sum16(zb[0]);
+                    if (p == 0 && n < W) PINN_ADD_S(&gbias[n], bs);
+                    PINN_SB();
+                }
+            }
+            PINN_REFRESH();
+            if (TAIL) {
+                float yt[RR][J];
+#pragma unroll
+                for (int e = 0; e < R; ++e) {
+                    float z[J], w[K + 1], zb[J];
+                    if (hl > 0) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vp, zs + 2 * ZY + (e * J + j) * 16);
+                    } else {
+                        z0_tail(e, z);
+                    }
+#pragma unroll
+                    for (int j = 0; j < J; ++j) yt[e][j] = sb_load1(srs, vp, zs + 2 * ZY + TS + (e * J + j) * 16);
+                    w_from_y<K>(yt[e], w);
+                    tanh_jet_bwd<K, KT>(z, yt[e], w, At[e], zb);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) At[e][j] = zb[j];
+                    const float bs = row_sum16(zb[0]);
+                    if (lane == 0) PINN_ADD_S(&gbias[NM + e], bs);
+                }
+                // tail x tail block of Wb_l
+#pragma unroll
+                for (int e = 0; e < R; ++e)
+#pragma unroll
+                    for (int e2 = 0; e2 < R; ++e2) {
+                        float v = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], yt[e2][j], v);
+                        v = row_sum16(v);
+                        if (lane == 0) PINN_ADD_S(&gtr[e * W + NM + e2], v);
+                    }
+            }
         }
 
-        // ---- first layer gradients from G/Gt = adjoint of z_0 ----
+
+#if PINN_CUT == 5
+        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
+          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
+#endif
+        // ---- first layer gradients from A/At = adjoint of z_0 ----
+        PINN_REFRESH();
+        PINN_XT_FETCH();
         {
-            float *gw0 = gacc + d.woff[0];
+            float *gw0 = gs;
 #pragma unroll
             for (int T = 0; T < NT; ++T)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float g0 = G[T][0][r];
+                    const float g0 = A[T][0][r];
                     float gx = g0 * hx, gt = g0 * ht;
-                    if (K >= 1) gx = fmaf(G[T][K >= 1 ? 1 : 0][r], sx, gx);
-                    if (KT >= 1) gt = fmaf(G[T][KT >= 1 ? K + 1 : 0][r], stt, gt);
+                    if (K >= 1) gx = fmaf(A[T][K >= 1 ? 1 : 0][r], sx, gx);
+                    if (KT >= 1) gt = fmaf(A[T][KT >= 1 ? K + 1 : 0][r], stt, gt);
                     gx = row_sum16(gx);
                     gt = row_sum16(gt);
                     const int n = 16 * T + 4 * q + r;
                     if (p == 0 && n < W) {
-                        atomicAdd(&gw0[2 * n], gx);
-                        atomicAdd(&gw0[2 * n + 1], gt);
+                        PINN_ADD_S(&gw0[2 * n], gx);
+                        PINN_ADD_S(&gw0[2 * n + 1], gt);
                     }
                 }
             if (TAIL) {
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
-                    const float g0 = Gt[e][0];
+                    const float g0 = At[e][0];
                     float gx = g0 * hx, gt = g0 * ht;
-                    if (K >= 1) gx = fmaf(Gt[e][K >= 1 ? 1 : 0], sx, gx);
-                    if (KT >= 1) gt = fmaf(Gt[e][KT >= 1 ? K + 1 : 0], stt, gt);
+                    if (K >= 1) gx = fmaf(At[e][K >= 1 ? 1 : 0], sx, gx);
+                    if (KT >= 1) gt = fmaf(At[e][KT >= 1 ? K + 1 : 0], stt, gt);
                     gx = row_sum16(gx);
                     gt = row_sum16(gt);
                     if (lane == 0) {
-                        atomicAdd(&gw0[2 * (NM + e)], gx);
-                        atomicAdd(&gw0[2 * (NM + e) + 1], gt);
+                        PINN_ADD_S(&gw0[2 * (NM + e)], gx);
+                        PINN_ADD_S(&gw0[2 * (NM + e) + 1], gt);
                     }
                 }
             }
         }
     }
 
+    PINN_REFRESH();
     if (MODE != MODE_FWD) {
         if (MODE == MODE_LOSS) {
             for (int c = 0; c < nf; ++c) {
                 const float s = wave_sum(lsum[c]);
-                if (lane == 0) atomicAdd(&gacc[P + c], s);
+                if (lane == 0) atomicAdd(&gs[L.gs_loss + c], s);
             }
         }
         __syncthreads();
+        // parameter order out of the compact block and the accumulator images
         float *slab = a.slab + (long long)blockIdx.x * (P + 2);
-        for (int i = tid; i < P + 2; i += MFMA_BLOCK) slab[i] = gacc[i];
+        for (int i = tid; i < P + 2; i += MFMA_BLOCK) {
+            float v;
+            if (i >= P) {
+                v = gs[L.gs_loss + (i - P)];
+            } else {
+                int l = 0;
+                while (l + 1 < n_lin && i >= d.woff[l + 1]) ++l;
+                const int fi = d.widths[l], fo = d.widths[l + 1];
+                const int rel = i - d.woff[l];
+                if (rel >= fi * fo) {                       // bias
+                    const int n = rel - fi * fo;
+                    v = (l == n_lin - 1) ? gs[L.gs_out + nout * W + n] : gblock(l)[n];
+                } else {
+                    const int o = rel / fi, c = rel - o * fi;
+                    if (l == 0) v = gs[rel];
+                    else if (l == n_lin - 1) v = gs[L.gs_out + rel];
+                    else if (o >= NM) v = gblock(l)[W + (o - NM) * W + c];
+                    else if (c >= NM) v = gblock(l)[W + R * W + o * R + (c - NM)];
+                    else {
+                        // accumulator (To,Ti): lane (p, q) register r holds Wb[16To + 4q + r][16Ti + p]
+                        const int To = o >> 4, q4 = (o & 15) >> 2, r = o & 3, Ti = c >> 4, pp = c & 15;
+                        v = lds[L.wimg + (((l - 1) * NT + To) * NT + Ti) * TILE + (q4 * 16 + pp) * 4 + r];
+                    }
+                }
+            }
+            slab[i] = v;
+        }
     }
 }
 
@@ -869,7 +1045,7 @@ inline bool mfma_supported(const KDesc &kd)
 #undef X
     default: return false;
     }
-    return lds <= 160 * 1024;
+    return lds <= (size_t)MFMA_LDS_LIMIT;
 }
 
 // floats of stash one wave needs for equation jets J
