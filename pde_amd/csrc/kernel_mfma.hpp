@@ -32,11 +32,13 @@
 // quads).
 //
 // Stash (global, private per wave, re-used every tile): per tanh layer  z main | y main | z tail | y tail.
-// z of the first layer is recomputed (it is affine in x,t) and y of the last tanh layer never leaves
-// registers, so neither is written.
+// The reverse sweep re-reads z (neuron by neuron, prefetched) and recomputes y and w = 1 - y^2 from it;
+// the stashed y only feeds the weight-gradient GEMM.  z of the first layer is recomputed (affine in
+// x,t); the last tanh layer keeps z in registers and is never stashed.
 //
 // tanh jets / residuals: jet_math.hpp.  Reference semantics as kernel_valu.hpp.
 #pragma once
+#include <type_traits>
 #include "jet_math.hpp"
 #include "pinn_common.hpp"
 
@@ -52,6 +54,7 @@ constexpr int MFMA_WAVES = MFMA_BLOCK / 64;
 constexpr int MFMA_LDS_LIMIT = 160 * 1024;
 constexpr int STAGE_ROW = 20;                  // floats per point row of the staging image (16 + pad: no bank conflicts)
 constexpr int STAGE_TILE = 16 * STAGE_ROW;
+constexpr int ZTL_J = 12;                      // >= the largest jet length J of any equation
 
 template <int W> struct WidthCfg {
     static constexpr int REM = W % 16;
@@ -89,6 +92,8 @@ struct MfmaLayout {   // offsets in floats into dynamic LDS
     int locks;        // one int per hidden->hidden layer
     int stage;        // per wave NT*STAGE_TILE
     int xt;           // per wave [2][64]: the scaled coordinates of the tile's points, parked between the sweeps
+    int ztl;          // per wave [R][ZTL_J][16]: tail rows of Zb, [component][point], for the weight-gradient phase
+    int atl;          // per wave [R][ZTL_J][16]: the tail registers, parked while the tiled neurons are processed
     int total;
 };
 
@@ -111,6 +116,8 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     L.locks = off; off += ((d.n_lin - 2 + 3) / 4) * 4 + 4;
     L.stage = off; off += MFMA_WAVES * C::NT * STAGE_TILE;
     L.xt = off; off += MFMA_WAVES * 128;
+    L.ztl = off; off += MFMA_WAVES * C::R * ZTL_J * 16;
+    L.atl = off; off += MFMA_WAVES * C::R * ZTL_J * 16;
     L.total = off;
     return L;
 }
@@ -134,6 +141,9 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
 #endif
 #ifndef PINN_CUT
 #define PINN_CUT 0
+#endif
+#ifndef PINN_ZPF
+#define PINN_ZPF 2           // reverse sweep: z of a neuron is requested this many neurons ahead
 #endif
 #define PINN_ADD_S(addr, v) do { if (!PINN_ABL_SATOM || rt_false) atomicAdd(addr, v); } while (0)
 
@@ -212,6 +222,7 @@ __device__ __forceinline__ float sb_load1(__amdgpu_buffer_rsrc_t rs, int voff, i
 // unrolled jet arithmetic of a neuron past the exec-masked atomics into the block of its first use
 // (a whole phase later) and spills the inputs instead.
 __device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
 
 // Workgroup-level spin lock in LDS (lane 0 spins, the wave stays converged).  All eight waves of the
 // workgroup are resident and make progress independently, so the holder always gets to release.
@@ -325,6 +336,9 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f / (d.ubx - d.lbx))));
     const float stt = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f / (d.ubt - d.lbt))));
     float *const xtp = lds + L.xt + wv * 128;
+    float *const ztl = lds + L.ztl + wv * (R * ZTL_J * 16);
+    float *const atl = lds + L.atl + wv * (R * ZTL_J * 16);
+    static_assert(J <= ZTL_J, "ZTL_J too small");
 
     for (long long tile = wave_g; tile < ntiles; tile += nwaves) {
         PINN_REFRESH();
@@ -344,6 +358,12 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
         // The one register-resident set: activations on the way up, adjoints on the way down.
         f32x4 A[NT][J];
         float At[RR][J];       // tail neurons (same value in all four lane quads)
+        // The reverse sweep's per-neuron loops need every register they can get: the tail set is parked
+        // in LDS around them.
+#define PINN_AT_PARK() do { if (TAIL) { if (q == 0) { _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
+            atl[(e * ZTL_J + j) * 16 + p] = At[e][j]; } } } while (0)
+#define PINN_AT_FETCH() do { if (TAIL) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
+            At[e][j] = atl[(e * ZTL_J + j) * 16 + p]; } } while (0)
 
         // first-layer pre-activation jets (also recomputed in the reverse sweep: they are affine in (x,t),
         // so they are never stashed).  Weights of tile T as three b128 LDS reads, then neuron r of them.
@@ -371,9 +391,39 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             if (KT >= 1) z[KT >= 1 ? K + 1 : 0] = wt * stt;
         };
 
+        // Output-layer partial sums.  The LAST tanh layer keeps its pre-activations z in A/At (they go
+        // straight into the reverse sweep, which recomputes y from z everywhere); its outputs y only
+        // exist neuron by neuron, feeding these sums.
+        float u[MAXOUT][J];
+#pragma unroll
+        for (int o = 0; o < MAXOUT; ++o)
+#pragma unroll
+            for (int j = 0; j < J; ++j) u[o][j] = 0.0f;
+        // y of tiled neuron n (lane-local partial sums; reduced over the lane quads at the end)
+        auto out_acc_main = [&](int n, const float (&y)[J]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int o = 0; o < MAXOUT; ++o)
+                if (o < nout) {
+                    const float wo = io[C::O_WOUT + o * NM + n];
+#pragma unroll
+                    for (int j = 0; j < J; ++j) u[o][j] = fmaf(wo, y[j], u[o][j]);
+                }
+        };
+        // y of tail neuron e: the value is replicated over the four quads, so only quad 0 adds it
+        auto out_acc_tail = [&](int e, const float (&y)[J]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int o = 0; o < MAXOUT; ++o)
+                if (o < nout) {
+                    const float wo = q == 0 ? io[C::O_WOUTT + o * 4 + e] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) u[o][j] = fmaf(wo, y[j], u[o][j]);
+                }
+        };
+
         // ---- first layer (2 -> W), VALU ----
         {
-            const bool keep_y = (MODE != MODE_FWD) && NH > 1;
+            const bool topl = NH == 1;
+            const bool keep_y = (MODE != MODE_FWD) && !topl;
 #pragma unroll
             for (int T = 0; T < NT; ++T) {
                 const W0 w0 = w0_tile(T);
@@ -384,13 +434,19 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                     tanh_jet_fwd<K, KT>(z, y, w);
 #pragma unroll
                     for (int j = 0; j < J; ++j) pin(y[j]);
+                    if (topl) {
+                        out_acc_main(16 * T + 4 * q + r, y);
 #pragma unroll
-                    for (int j = 0; j < J; ++j) A[T][j][r] = y[j];
-                    if (keep_y) {
+                        for (int j = 0; j < J; ++j) A[T][j][r] = z[j];
+                    } else {
 #pragma unroll
-                        for (int j = 0; j < J; ++j) sb_store1(srs, vyn, ZY + (T * J + j) * TILE + r * 16, y[j]);
+                        for (int j = 0; j < J; ++j) A[T][j][r] = y[j];
                     }
                     PINN_SB();
+                }
+                if (keep_y) {
+#pragma unroll
+                    for (int j = 0; j < J; ++j) sb_store4(srs, vnat, ZY + (T * J + j) * TILE, A[T][j]);
                 }
             }
 #pragma unroll
@@ -400,12 +456,20 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             if (TAIL) {
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
-                    float z[J], w[K + 1];
+                    float z[J], y[J], w[K + 1];
                     z0_tail(e, z);
-                    tanh_jet_fwd<K, KT>(z, At[e], w);
-                    if (keep_y && q == 0) {
+                    tanh_jet_fwd<K, KT>(z, y, w);
+                    if (topl) {
+                        out_acc_tail(e, y);
 #pragma unroll
-                        for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + TS + (e * J + j) * 16, At[e][j]);
+                        for (int j = 0; j < J; ++j) At[e][j] = z[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) At[e][j] = y[j];
+                        if (keep_y && q == 0) {
+#pragma unroll
+                            for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + TS + (e * J + j) * 16, y[j]);
+                        }
                     }
                 }
             }
@@ -421,7 +485,8 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             PINN_REFRESH();
             const float *img = lds + L.hh + (l - 1) * C::HH;
             const int zs = l * LAYER_STASH;   // stash offset (floats) of this layer
-            const bool keep_y = (MODE != MODE_FWD) && l < NH - 1;
+            const bool topl = l == NH - 1;
+            const bool keep_y = (MODE != MODE_FWD) && !topl;
             float zt[RR][J];
 #pragma unroll
             for (int e = 0; e < RR; ++e)
@@ -442,14 +507,18 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                             for (int r = 0; r < 4; ++r) acc[To][r] = fmaf(wc[r], At[e][j], acc[To][r]);
                         }
                     }
+                    // A fragments: lane (m = p, q) holds W[16To + m][16Ti + 4q + r], r = 0..3; the NT reads
+                    // of this output tile are issued together and waited for once
+                    f32x4 wf[NT];
 #pragma unroll
-                    for (int Ti = 0; Ti < NT; ++Ti) {
-                        // A fragment: lane (m = p, q) holds W[16To + m][16Ti + 4q + r], r = 0..3
-                        const f32x4 wf = *(const f32x4 *)&img[(16 * To + p) * S + 16 * Ti + 4 * q];
+                    for (int Ti = 0; Ti < NT; ++Ti) wf[Ti] = *(const f32x4 *)&img[(16 * To + p) * S + 16 * Ti + 4 * q];
+#pragma unroll
+                    for (int Ti = 0; Ti < NT; ++Ti) pin(wf[Ti]);
+#pragma unroll
+                    for (int Ti = 0; Ti < NT; ++Ti)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (16 * Ti + r < W) acc[To] = mfma4(wf[r], A[Ti][j][r], acc[To]);
-                    }
+                            if (16 * Ti + r < W) acc[To] = mfma4(wf[Ti][r], A[Ti][j][r], acc[To]);
                     PINN_SB();
                 }
                 PINN_SB();
@@ -476,7 +545,8 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                 for (int To = 0; To < NT; ++To) A[To][j] = acc[To];
                 PINN_JB();
             }
-            // A = z of this layer: stash it and apply tanh in place, neuron by neuron
+            // A = z of this layer.  Last tanh layer: z stays, y feeds the output sums.  Otherwise: stash z
+            // and y, tanh in place, neuron by neuron.
             PINN_REFRESH();
 #pragma unroll
             for (int To = 0; To < NT; ++To)
@@ -485,37 +555,48 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                     float z[J], y[J], w[K + 1];
 #pragma unroll
                     for (int j = 0; j < J; ++j) z[j] = A[To][j][r];
-                    if (MODE != MODE_FWD) {
+                    if (keep_y) {
 #pragma unroll
                         for (int j = 0; j < J; ++j) sb_store1(srs, vyn, zs + (To * J + j) * TILE + r * 16, z[j]);
                     }
                     tanh_jet_fwd<K, KT>(z, y, w);
 #pragma unroll
                     for (int j = 0; j < J; ++j) pin(y[j]);
+                    if (topl) {
+                        out_acc_main(16 * To + 4 * q + r, y);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < J; ++j) A[To][j][r] = y[j];
-                    if (keep_y) {
-#pragma unroll
-                        for (int j = 0; j < J; ++j) sb_store1(srs, vyn, zs + ZY + (To * J + j) * TILE + r * 16, y[j]);
+                        for (int j = 0; j < J; ++j) A[To][j][r] = y[j];
                     }
                     PINN_SB();
+                    if (r == 3 && keep_y) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) sb_store4(srs, vnat, zs + ZY + (To * J + j) * TILE, A[To][j]);
+                    }
                 }
             if (TAIL) {
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
-                    float w[K + 1];
-                    tanh_jet_fwd<K, KT>(zt[e], At[e], w);
-                    if (MODE != MODE_FWD && q == 0) {
+                    float y[J], w[K + 1];
+                    tanh_jet_fwd<K, KT>(zt[e], y, w);
+                    if (topl) {
+                        out_acc_tail(e, y);
 #pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            sb_store1(srs, vp, zs + 2 * ZY + (e * J + j) * 16, zt[e][j]);
-                            if (keep_y) sb_store1(srs, vp, zs + 2 * ZY + TS + (e * J + j) * 16, At[e][j]);
+                        for (int j = 0; j < J; ++j) At[e][j] = zt[e][j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) At[e][j] = y[j];
+                        if (keep_y && q == 0) {
+#pragma unroll
+                            for (int j = 0; j < J; ++j) {
+                                sb_store1(srs, vp, zs + 2 * ZY + (e * J + j) * 16, zt[e][j]);
+                                sb_store1(srs, vp, zs + 2 * ZY + TS + (e * J + j) * 16, y[j]);
+                            }
                         }
                     }
                 }
             }
         }
-
 
 #if PINN_CUT == 2
         { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
@@ -526,34 +607,15 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
         float D[MAXOUT][J], Tt[MAXOUT][J];
 #pragma unroll
         for (int o = 0; o < MAXOUT; ++o) {
-            float u[J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) u[j] = 0.0f;
             if (o < nout) {
 #pragma unroll
-                for (int T = 0; T < NT; ++T) {
-                    const f32x4 wo = *(const f32x4 *)&io[C::O_WOUT + o * NM + 16 * T + 4 * q];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int j = 0; j < J; ++j) u[j] = fmaf(wo[r], A[T][j][r], u[j]);
-                }
-#pragma unroll
-                for (int j = 0; j < J; ++j) u[j] = quad_rows_sum(u[j]);
-                if (TAIL) {
-#pragma unroll
-                    for (int e = 0; e < R; ++e) {
-                        const float wo = io[C::O_WOUTT + o * 4 + e];
-#pragma unroll
-                        for (int j = 0; j < J; ++j) u[j] = fmaf(wo, At[e][j], u[j]);
-                    }
-                }
-                u[0] += io[C::O_BOUT + o];
+                for (int j = 0; j < J; ++j) u[o][j] = quad_rows_sum(u[o][j]);
+                u[o][0] += io[C::O_BOUT + o];
             }
 #pragma unroll
-            for (int k = 0; k <= K; ++k) D[o][k] = factorial(k) * u[k];
+            for (int k = 0; k <= K; ++k) D[o][k] = factorial(k) * u[o][k];
 #pragma unroll
-            for (int k = 0; k < KT; ++k) Tt[o][k] = factorial(k) * u[K + 1 + k];
+            for (int k = 0; k < KT; ++k) Tt[o][k] = factorial(k) * u[o][K + 1 + k];
         }
         float f[MAXOUT] = {0.0f, 0.0f};
         Residual<EQ>::eval(D, Tt, d.coef, nout, f);
@@ -616,62 +678,23 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                 if (lane == 0) PINN_ADD_S(&gs[L.gs_out + nout * W + o], bs);
             }
 
-        // ---- top tanh layer (NH-1): y is still in registers, its adjoint is the outer product
-        //      Wout^T ub, and the output layer's weight gradient is formed on the way.  A/At: y -> Zb. ----
+        // ---- top tanh layer (NH-1): A/At hold its pre-activations z; y is recomputed, its adjoint is the
+        //      outer product Wout^T ub, and the output layer's weight gradient is formed on the way.
+        //      A/At: z -> Zb. ----
         {
             const int hl = NH - 1;
-            const int zs = hl * LAYER_STASH;
             float *gbias = gblock(hl);
-            if (hl == 0) PINN_XT_FETCH();
-            if (TAIL) {
+            PINN_AT_PARK();
+            PINN_SB();
 #pragma unroll
-                for (int e = 0; e < R; ++e) {
-                    float z[J], w[K + 1], yb[J], zb[J];
-                    if (hl > 0) {
-#pragma unroll
-                        for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vp, zs + 2 * ZY + (e * J + j) * 16);
-                    } else {
-                        z0_tail(e, z);
-                    }
-#pragma unroll
-                    for (int j = 0; j < J; ++j) yb[j] = 0.0f;
-#pragma unroll
-                    for (int o = 0; o < MAXOUT; ++o)
-                        if (o < nout) {
-                            const float wo = io[C::O_WOUTT + o * 4 + e];
-                            float v = 0.0f;
-#pragma unroll
-                            for (int j = 0; j < J; ++j) {
-                                v = fmaf(ub[o][j], At[e][j], v);
-                                yb[j] = fmaf(wo, ub[o][j], yb[j]);
-                            }
-                            v = row_sum16(v);
-                            if (lane == 0) PINN_ADD_S(&gs[L.gs_out + o * W + NM + e], v);
-                        }
-                    w_from_y<K>(At[e], w);
-                    tanh_jet_bwd<K, KT>(z, At[e], w, yb, zb);
-#pragma unroll
-                    for (int j = 0; j < J; ++j) At[e][j] = zb[j];
-                    const float bs = row_sum16(zb[0]);
-                    if (lane == 0) PINN_ADD_S(&gbias[NM + e], bs);
-                }
-            }
-#pragma unroll
-            for (int T = 0; T < NT; ++T) {
-                W0 w0;
-                if (hl == 0) w0 = w0_tile(T);
+            for (int T = 0; T < NT; ++T)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float z[J], y[J], w[K + 1], yb[J], zb[J];
                     const int n = 16 * T + 4 * q + r;
-                    if (hl > 0) {
 #pragma unroll
-                        for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vyn, zs + (T * J + j) * TILE + r * 16);
-                    } else {
-                        z0_main(w0, r, z);
-                    }
-#pragma unroll
-                    for (int j = 0; j < J; ++j) { y[j] = A[T][j][r]; yb[j] = 0.0f; }
+                    for (int j = 0; j < J; ++j) { z[j] = A[T][j][r]; yb[j] = 0.0f; }
+                    tanh_jet_fwd<K, KT>(z, y, w);
 #pragma unroll
                     for (int o = 0; o < MAXOUT; ++o)
                         if (o < nout) {
@@ -685,7 +708,6 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                             v = row_sum16(v);
                             if (p == 0 && n < W) PINN_ADD_S(&gs[L.gs_out + o * W + n], v);
                         }
-                    w_from_y<K>(y, w);
                     tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
 #pragma unroll
                     for (int j = 0; j < J; ++j) pin(zb[j]);
@@ -695,9 +717,35 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                     if (p == 0 && n < W) PINN_ADD_S(&gbias[n], bs);
                     PINN_SB();
                 }
+            PINN_AT_FETCH();
+            if (TAIL) {
+#pragma unroll
+                for (int e = 0; e < R; ++e) {
+                    float y[J], w[K + 1], yb[J], zb[J];
+                    tanh_jet_fwd<K, KT>(At[e], y, w);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) yb[j] = 0.0f;
+#pragma unroll
+                    for (int o = 0; o < MAXOUT; ++o)
+                        if (o < nout) {
+                            const float wo = io[C::O_WOUTT + o * 4 + e];
+                            float v = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) {
+                                v = fmaf(ub[o][j], y[j], v);
+                                yb[j] = fmaf(wo, ub[o][j], yb[j]);
+                            }
+                            v = row_sum16(v);
+                            if (lane == 0) PINN_ADD_S(&gs[L.gs_out + o * W + NM + e], v);
+                        }
+                    tanh_jet_bwd<K, KT>(At[e], y, w, yb, zb);
+#pragma unroll
+                    for (int j = 0; j < J; ++j) At[e][j] = zb[j];
+                    const float bs = row_sum16(zb[0]);
+                    if (lane == 0) PINN_ADD_S(&gbias[NM + e], bs);
+                }
             }
         }
-
 
 #if PINN_CUT == 4
         { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
@@ -720,12 +768,37 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                 for (int To = 0; To < NT; ++To)
 #pragma unroll
                     for (int Ti = 0; Ti < NT; ++Ti) wacc[To][Ti] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                // Software pipeline over the jet components: while the 36 MFMAs of component j run, the
+                // operands of j+1 are already on their way (stash b128 loads; Zb through the staging image).
+                //  B operand: lane (n = p, kk = q) gets y[16Ti + n][points 4kk .. 4kk+3]
+                //  A operand: Zb through the staging image [point][neuron] -> lane (m = p, kk = q) reads
+                //             Zb[16To + m][point 4kk + s]
+                float bop[2][NT][4];
+                // The tail rows of Zb are parked in LDS as [component][point]: their weight gradient against
+                // the tiled y_{l-1} is formed in the tanh layer below, where y_{l-1} is recomputed anyway.
+                if (TAIL) {
+                    if (q == 0) {
+#pragma unroll
+                        for (int e = 0; e < R; ++e)
+#pragma unroll
+                            for (int j = 0; j < J; ++j) ztl[(e * ZTL_J + j) * 16 + p] = At[e][j];
+                    }
+                }
+#pragma unroll
+                for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bop[0][Ti][s] = sb_load1(srs, vyn, yprev + (Ti * J + 0) * TILE + s * 16);
+                PINN_JB();
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                    // B operand: lane (n = p, kk = q) gets y[16Ti + n][points 4kk .. 4kk+3]
-                    f32x4 bop[NT];
+                    const int c = j & 1, nx = c ^ 1;
+                    // the stash loads of component j+1 are in flight while component j is processed
+                    if (j + 1 < J) {
 #pragma unroll
-                    for (int Ti = 0; Ti < NT; ++Ti) bop[Ti] = sb_load4(srs, vnat, yprev + (Ti * J + j) * TILE);
+                        for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) bop[nx][Ti][s] = sb_load1(srs, vyn, yprev + (Ti * J + j + 1) * TILE + s * 16);
+                    }
                     // A operand: Zb through the staging image [point][neuron] -> lane (m = p, kk = q) reads
                     // Zb[16To + m][point 4kk + s]
 #pragma unroll
@@ -736,13 +809,17 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                     for (int To = 0; To < NT; ++To)
 #pragma unroll
                         for (int s = 0; s < 4; ++s) aop[To][s] = stage[To * STAGE_TILE + (4 * q + s) * STAGE_ROW + p];
-                    PINN_LDS_FENCE();
+#pragma unroll
+                    for (int To = 0; To < NT; ++To)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) pin(aop[To][s]);
+                    PINN_SB();
 #pragma unroll
                     for (int To = 0; To < NT; ++To)
 #pragma unroll
                         for (int Ti = 0; Ti < NT; ++Ti)
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) wacc[To][Ti] = mfma4(aop[To][s], bop[Ti][s], wacc[To][Ti]);
+                            for (int s = 0; s < 4; ++s) wacc[To][Ti] = mfma4(aop[To][s], bop[c][Ti][s], wacc[To][Ti]);
                     PINN_JB();
                 }
                 // accumulator (To,Ti): lane (i = p, q) register r holds Wb[16To + 4q + r][16Ti + p]
@@ -760,12 +837,21 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                 }
                 PINN_SB();
                 if (TAIL) {
-                    // tiled rows x tail columns: Wb[o][NM+e] = sum_{p,k} Zb_k[o][p] * ytail_k[e][p]
+                    // tiled rows x tail columns: Wb[o][NM+e] = sum_{p,k} Zb_k[o][p] * ytail_k[e][p],
+                    // and the tail x tail corner
 #pragma unroll
                     for (int e = 0; e < R; ++e) {
                         float yp[J];
 #pragma unroll
                         for (int j = 0; j < J; ++j) yp[j] = sb_load1(srs, vp, yprev + ZY + TS + (e * J + j) * 16);
+#pragma unroll
+                        for (int e1 = 0; e1 < R; ++e1) {
+                            float v = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) v = fmaf(At[e1][j], yp[j], v);
+                            v = row_sum16(v);
+                            if (lane == 0) PINN_ADD_S(&gtr[e1 * W + NM + e], v);
+                        }
 #pragma unroll
                         for (int To = 0; To < NT; ++To)
 #pragma unroll
@@ -779,13 +865,15 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                     }
                 }
             }
+
+#if PINN_CUT == 41
+            { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
+              for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
+#endif
             PINN_SB();
             PINN_REFRESH();
 
             // Phase B: Yb^T[i][p] = sum_o W[o][i] Zb^T[o][p], one jet component at a time, in place.
-            // Ct keeps the tail rows of Zb: their weight gradient against the tiled y_{l-1} is formed
-            // below, where y_{l-1} is loaded anyway.
-            float Ct[RR][J];
             {
                 float Ht[RR][J];
 #pragma unroll
@@ -807,15 +895,22 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                                 for (int r = 0; r < 4; ++r) acc[Ti][r] = fmaf(wr[r], At[e][j], acc[Ti][r]);
                             }
                         }
+                        // A fragments: lane (m = p, q) holds W[16To + 4q + r][16Ti + m].  All 4*NT reads of this
+                        // output tile are issued together and waited for once.
+                        float wf[NT][4];
+#pragma unroll
+                        for (int To = 0; To < NT; ++To)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) wf[To][r] = img[(16 * To + 4 * q + r) * S + 16 * Ti + p];
+#pragma unroll
+                        for (int To = 0; To < NT; ++To)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) pin(wf[To][r]);
 #pragma unroll
                         for (int To = 0; To < NT; ++To)
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                if (16 * To + r < W) {
-                                    // A fragment: lane (m = p, q) holds W[16To + 4q + r][16Ti + m]
-                                    const float wf = img[(16 * To + 4 * q + r) * S + 16 * Ti + p];
-                                    acc[Ti] = mfma4(wf, A[To][j][r], acc[Ti]);
-                                }
+                                if (16 * To + r < W) acc[Ti] = mfma4(wf[To][r], A[To][j][r], acc[Ti]);
                         PINN_SB();
                     }
                     PINN_SB();
@@ -844,88 +939,103 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
 #pragma unroll
                 for (int e = 0; e < RR; ++e)
 #pragma unroll
-                    for (int j = 0; j < J; ++j) { Ct[e][j] = At[e][j]; At[e][j] = Ht[e][j]; }
+                    for (int j = 0; j < J; ++j) At[e][j] = Ht[e][j];
             }
 
+
+#if PINN_CUT == 42
+            { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
+              for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
+#endif
             // tanh layer hl = l-1: A/At = adjoint of y_hl -> adjoint of z_hl, in place
             PINN_REFRESH();
             const int hl = l - 1;
             const int zs = hl * LAYER_STASH;
             float *gbias = gblock(hl);
             if (hl == 0) PINN_XT_FETCH();
+            // z comes back from the stash neuron by neuron, PINN_ZPF neurons ahead of its use (one wave has
+            // only one other wave on its SIMD to hide the load latency behind); y and w are recomputed.
+            // The first tanh layer recomputes z instead.  Two instantiations of the same body, so that
+            // neither carries the other's registers (prefetch ring vs. first-layer weights).
+            auto rev_main = [&](auto first_tag) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(first_tag)::value;
+                constexpr int NQ = 4 * NT;
+                constexpr int RING = FIRST ? 1 : PINN_ZPF + 1;
+                float zr[RING][J];
+                auto zfetch = [&](int nidx, float (&z)[J]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int T = 0; T < NT; ++T) {
-                W0 w0;
-                if (hl == 0) w0 = w0_tile(T);
+                    for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vyn, zs + ((nidx >> 2) * J + j) * TILE + (nidx & 3) * 16);
+                };
+                if (!FIRST) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float z[J], y[J], w[K + 1], yb[J], zb[J];
-                    const int n = 16 * T + 4 * q + r;
-                    if (hl > 0) {
-#pragma unroll
-                        for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vyn, zs + (T * J + j) * TILE + r * 16);
-                    } else {
-                        z0_main(w0, r, z);
-                    }
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        y[j] = sb_load1(srs, vyn, zs + ZY + (T * J + j) * TILE + r * 16);
-                        yb[j] = A[T][j][r];
-                    }
-                    if (TAIL) {
-                        // tail rows of Wb_l against this neuron of y_hl
-#pragma unroll
-                        for (int e = 0; e < R; ++e) {
-                            float v = 0.0f;
-#pragma unroll
-                            for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], y[j], v);
-                            v = row_sum16(v);
-                            if (p == 0) PINN_ADD_S(&gtr[e * W + n], v);
-                        }
-                    }
-                    w_from_y<K>(y, w);
-                    tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
-#pragma unroll
-                    for (int j = 0; j < J; ++j) pin(zb[j]);
-#pragma unroll
-                    for (int j = 0; j < J; ++j) A[T][j][r] = zb[j];
-                    const float bs = row_sum16(zb[0]);
-                    if (p == 0 && n < W) PINN_ADD_S(&gbias[n], bs);
-                    PINN_SB();
+                    for (int k = 0; k < PINN_ZPF; ++k)
+                        if (k < NQ) zfetch(k, zr[k % RING]);
                 }
-            }
+                PINN_SB();
+#pragma unroll
+                for (int T = 0; T < NT; ++T) {
+                    W0 w0;
+                    if (FIRST) w0 = w0_tile(T);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float z[J], y[J], w[K + 1], yb[J], zb[J];
+                        const int nidx = 4 * T + r;
+                        const int n = 16 * T + 4 * q + r;
+                        if (!FIRST) {
+                            if (nidx + PINN_ZPF < NQ) zfetch(nidx + PINN_ZPF, zr[(nidx + PINN_ZPF) % RING]);
+#pragma unroll
+                            for (int j = 0; j < J; ++j) z[j] = zr[nidx % RING][j];
+                        } else {
+                            z0_main(w0, r, z);
+                        }
+#pragma unroll
+                        for (int j = 0; j < J; ++j) yb[j] = A[T][j][r];
+                        tanh_jet_fwd<K, KT>(z, y, w);
+                        if (TAIL) {
+                            // tail rows of Wb_l against this neuron of y_hl (Zbtail of layer l: parked in LDS)
+#pragma unroll
+                            for (int e = 0; e < R; ++e) {
+                                float v = 0.0f;
+#pragma unroll
+                                for (int j = 0; j < J; ++j) v = fmaf(ztl[(e * ZTL_J + j) * 16 + p], y[j], v);
+                                v = row_sum16(v);
+                                if (p == 0) PINN_ADD_S(&gtr[e * W + n], v);
+                            }
+                        }
+                        tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
+#pragma unroll
+                        for (int j = 0; j < J; ++j) pin(zb[j]);
+#pragma unroll
+                        for (int j = 0; j < J; ++j) A[T][j][r] = zb[j];
+                        const float bs = row_sum16(zb[0]);
+                        if (p == 0 && n < W) PINN_ADD_S(&gbias[n], bs);
+                        PINN_SB();
+                    }
+                }
+            };
+            PINN_AT_PARK();
+            PINN_SB();
+            if (hl > 0) rev_main(std::false_type{});
+            else rev_main(std::true_type{});
+            PINN_AT_FETCH();
             PINN_REFRESH();
             if (TAIL) {
-                float yt[RR][J];
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
-                    float z[J], w[K + 1], zb[J];
+                    float z[J], y[J], w[K + 1], zb[J];
                     if (hl > 0) {
 #pragma unroll
                         for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vp, zs + 2 * ZY + (e * J + j) * 16);
                     } else {
                         z0_tail(e, z);
                     }
-#pragma unroll
-                    for (int j = 0; j < J; ++j) yt[e][j] = sb_load1(srs, vp, zs + 2 * ZY + TS + (e * J + j) * 16);
-                    w_from_y<K>(yt[e], w);
-                    tanh_jet_bwd<K, KT>(z, yt[e], w, At[e], zb);
+                    tanh_jet_fwd<K, KT>(z, y, w);
+                    tanh_jet_bwd<K, KT>(z, y, w, At[e], zb);
 #pragma unroll
                     for (int j = 0; j < J; ++j) At[e][j] = zb[j];
                     const float bs = row_sum16(zb[0]);
                     if (lane == 0) PINN_ADD_S(&gbias[NM + e], bs);
                 }
-                // tail x tail block of Wb_l
-#pragma unroll
-                for (int e = 0; e < R; ++e)
-#pragma unroll
-                    for (int e2 = 0; e2 < R; ++e2) {
-                        float v = 0.0f;
-#pragma unroll
-                        for (int j = 0; j < J; ++j) v = fmaf(Ct[e][j], yt[e2][j], v);
-                        v = row_sum16(v);
-                        if (lane == 0) PINN_ADD_S(&gtr[e * W + NM + e2], v);
-                    }
             }
         }
 
