@@ -189,6 +189,15 @@ def main():
     k_avg = float(np.mean(kt))
     flops = FLOPS_PER_POINT[w["eq"]] * n_local
     achieved = flops / k_avg / 1e12
+    # HBM bytes per launch of that kernel: from the committed rocprofv3 PMC passes (profiles/traffic.json,
+    # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE), when this exact workload / size / kernel was profiled
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as fh:
+            ent = json.load(fh).get("%s|%d|%s" % (w["eq"], n_local, {1: "valu", 2: "mfma"}[eng.kernel_kind]))
+        traffic = ent["bytes"] if ent else None
+    except (OSError, ValueError, KeyError):
+        traffic = None
 
     # ---- full training step (IC/BC terms + Adam) ----
     train_sps = None
@@ -224,11 +233,12 @@ def main():
                        "kernel": {1: "valu", 2: "mfma"}[eng.kernel_kind]},
             "train_steps_per_s": train_sps,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "kernel_ms": 1e3 * k_avg,
                          "algorithmic_flops_per_point": FLOPS_PER_POINT[w["eq"]],
                          "note": "FP32 compute roofline (vector == f32-input MFMA peak); "
-                                 "HBM traffic is 8 B/point algorithmic"},
+                                 "algorithmic HBM traffic is 8 B/point (x, t in); `traffic` is the measured "
+                                 "per-launch HBM bytes, almost all of it the per-wave jet stash (DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w)

@@ -333,8 +333,10 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     float lsum[MAXOUT] = {0.0f, 0.0f};
 
     // wave-uniform: keep them in SGPRs
-    const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f / (d.ubx - d.lbx))));
-    const float stt = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 2.0f / (d.ubt - d.lbt))));
+    auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    const float dxr = uni(d.ubx - d.lbx), dtr = uni(d.ubt - d.lbt);
+    const float sx = uni(2.0f / dxr), stt = uni(2.0f / dtr);
+    const float two_scale = uni(2.0f * a.scale);
     float *const xtp = lds + L.xt + wv * 128;
     float *const ztl = lds + L.ztl + wv * (R * ZTL_J * 16);
     float *const atl = lds + L.atl + wv * (R * ZTL_J * 16);
@@ -342,15 +344,14 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
 
     for (long long tile = wave_g; tile < ntiles; tile += nwaves) {
         PINN_REFRESH();
-        const long long pt = tile * 16 + p;
-        const bool valid = pt < a.n;
-        const long long pc = valid ? pt : a.n - 1;
+        // (point index and validity are re-derived where they are needed again, not kept live)
+        const long long pc = (tile * 16 + p < a.n) ? tile * 16 + p : a.n - 1;
         const float xv = a.x[pc * a.stride], tv = a.t[pc * a.stride];
         // scaled coordinates: needed by the first layer now and again at the very end of the reverse
         // sweep; in between they are parked in LDS (PINN_XT_PARK / PINN_XT_FETCH) instead of being
         // spilled to scratch by the register allocator
-        float hx = 2.0f * (xv - d.lbx) / (d.ubx - d.lbx) - 1.0f;
-        float ht = 2.0f * (tv - d.lbt) / (d.ubt - d.lbt) - 1.0f;
+        float hx = 2.0f * (xv - d.lbx) / dxr - 1.0f;
+        float ht = 2.0f * (tv - d.lbt) / dtr - 1.0f;
 #define PINN_XT_PARK() do { xtp[lane] = hx; xtp[64 + lane] = ht; } while (0)
 #define PINN_XT_FETCH() do { asm volatile("" ::: "memory"); hx = xtp[lane]; ht = xtp[64 + lane]; } while (0)
         if (MODE != MODE_FWD) PINN_XT_PARK();
@@ -617,6 +618,8 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
 #pragma unroll
             for (int k = 0; k < KT; ++k) Tt[o][k] = factorial(k) * u[o][K + 1 + k];
         }
+        const long long pt = tile * 16 + p;
+        const bool valid = pt < a.n;
         float f[MAXOUT] = {0.0f, 0.0f};
         Residual<EQ>::eval(D, Tt, d.coef, nout, f);
 
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
         float fb[MAXOUT] = {0.0f, 0.0f};
         for (int c = 0; c < nf; ++c) {
             if (MODE == MODE_LOSS) {
-                fb[c] = valid ? 2.0f * a.scale * f[c] : 0.0f;
+                fb[c] = valid ? two_scale * f[c] : 0.0f;
                 lsum[c] += (valid && q == 0) ? f[c] * f[c] : 0.0f;
             } else {
                 fb[c] = valid ? a.gbar[pt * nf + c] : 0.0f;
