@@ -49,12 +49,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef PINN_MFMA_BLOCK
 #define PINN_MFMA_BLOCK 512
 #endif
-constexpr int MFMA_BLOCK = PINN_MFMA_BLOCK;
-constexpr int MFMA_WAVES = MFMA_BLOCK / 64;
+constexpr int MFMA_MAX_WAVES = 8;
 constexpr int MFMA_LDS_LIMIT = 160 * 1024;
 constexpr int STAGE_ROW = 20;                  // floats per point row of the staging image (16 + pad: no bank conflicts)
 constexpr int STAGE_TILE = 16 * STAGE_ROW;
-constexpr int ZTL_J = 12;                      // >= the largest jet length J of any equation
 
 template <int W> struct WidthCfg {
     static constexpr int REM = W % 16;
@@ -63,6 +61,17 @@ template <int W> struct WidthCfg {
     static constexpr int R = TAIL ? REM : 0;                   // tail neurons on the VALU
     static constexpr int RR = R > 0 ? R : 1;                   // array extent
     static constexpr int NM = 16 * NT;                         // neurons covered by tiles
+    // Workgroup shape.  Up to width 64 the weights, the weight-gradient images and the staging area of
+    // eight waves fit in LDS together: two waves per SIMD, <= 256 registers each.  Wider layers
+    // (GNSS, width 100 = 96 + 4) fill LDS with the weights alone: four waves (one per SIMD, 512
+    // registers: the 36 weight-gradient accumulator tiles of a layer live in AGPRs), Zb staged STG
+    // tiles at a time, and ALL gradient accumulation goes to the workgroup's global slab with
+    // hardware float atomics (L2-resident: 123 KB per workgroup) instead of LDS.
+    static constexpr bool WIDE = W > 64;
+    static constexpr int WAVES = WIDE ? 4 : PINN_MFMA_BLOCK / 64;
+    static constexpr int BLOCK = 64 * WAVES;
+    static constexpr bool WGLOBAL = WIDE;
+    static constexpr int STG = WIDE ? (NT + 1) / 2 : NT;       // Zb tiles staged per pass of the weight-gradient GEMM
     static constexpr int S = NM + 4;                           // row stride of the main weight image
     // one hidden->hidden layer image in LDS (floats)
     static constexpr int O_BIAS = NM * S;          // [NM]
@@ -92,12 +101,12 @@ struct MfmaLayout {   // offsets in floats into dynamic LDS
     int locks;        // one int per hidden->hidden layer
     int stage;        // per wave NT*STAGE_TILE
     int xt;           // per wave [2][64]: the scaled coordinates of the tile's points, parked between the sweeps
-    int ztl;          // per wave [R][ZTL_J][16]: tail rows of Zb, [component][point], for the weight-gradient phase
-    int atl;          // per wave [R][ZTL_J][16]: the tail registers, parked while the tiled neurons are processed
+    int ztl;          // per wave [R][J][16]: tail rows of Zb, [component][point], for the weight-gradient phase
+    int atl;          // per wave [R][J][16]: the tail registers, parked while the tiled neurons are processed
     int total;
 };
 
-template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &d)
+template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &d, int J)
 {
     typedef WidthCfg<W> C;
     MfmaLayout L;
@@ -110,14 +119,15 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     L.gs_hid_stride = W + C::R * W + C::NM * C::R;
     L.gs_out = L.gs_hid + (d.n_lin - 2) * L.gs_hid_stride;
     L.gs_loss = L.gs_out + d.nout * W + d.nout;
+    if (C::WGLOBAL) L.gs_loss = 0;                 // only the loss sums stay in LDS
     L.gs_size = ((L.gs_loss + 2 + 3) / 4) * 4;
     off += L.gs_size;
-    L.wimg = off; off += (d.n_lin - 2) * C::NT * C::NT * 256;
+    L.wimg = off; off += C::WGLOBAL ? 0 : (d.n_lin - 2) * C::NT * C::NT * 256;
     L.locks = off; off += ((d.n_lin - 2 + 3) / 4) * 4 + 4;
-    L.stage = off; off += MFMA_WAVES * C::NT * STAGE_TILE;
-    L.xt = off; off += MFMA_WAVES * 128;
-    L.ztl = off; off += MFMA_WAVES * C::R * ZTL_J * 16;
-    L.atl = off; off += MFMA_WAVES * C::R * ZTL_J * 16;
+    L.stage = off; off += C::WAVES * C::STG * STAGE_TILE;
+    L.xt = off; off += C::WAVES * 128;
+    L.ztl = off; off += C::WAVES * C::R * J * 16;
+    L.atl = off; off += C::WAVES * C::R * J * 16;
     L.total = off;
     return L;
 }
@@ -145,7 +155,7 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
 #ifndef PINN_ZPF
 #define PINN_ZPF 2           // reverse sweep: z of a neuron is requested this many neurons ahead
 #endif
-#define PINN_ADD_S(addr, v) do { if (!PINN_ABL_SATOM || rt_false) atomicAdd(addr, v); } while (0)
+#define PINN_ADD_S(addr, v) do { if (!PINN_ABL_SATOM || rt_false) { if (WGLOBAL) unsafeAtomicAdd(addr, v); else atomicAdd(addr, v); } } while (0)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
@@ -244,11 +254,12 @@ __device__ __forceinline__ void lds_unlock(int *lk, int lane)
 }
 
 template <int EQ, int W, int MODE>
-__global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, float *stash)
+__global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArgs a, float *stash)
 {
     typedef WidthCfg<W> C;
     constexpr int NT = C::NT, R = C::R, RR = C::RR, NM = C::NM, S = C::S;
-    constexpr bool TAIL = C::TAIL;
+    constexpr bool TAIL = C::TAIL, WGLOBAL = C::WGLOBAL;
+    constexpr int MFMA_BLOCK = C::BLOCK, MFMA_WAVES = C::WAVES, STG = C::STG;
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
     constexpr int TILE = 256;                      // floats of one 16x16 stash image
     constexpr int ZY = NT * J * TILE;              // main z (or y) images of one hidden layer
@@ -256,7 +267,8 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     constexpr int LAYER_STASH = 2 * ZY + 2 * TS;   // z main | y main | z tail | y tail
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
-    const MfmaLayout L = mfma_layout<W>(d);
+    constexpr int ZTL_J = EqTraits<EQ>::K + 1 + EqTraits<EQ>::KT;
+    const MfmaLayout L = mfma_layout<W>(d, ZTL_J);
     const int n_lin = d.n_lin;
     const int NH = n_lin - 1;                      // tanh layers
     const int nout = d.nout;
@@ -313,11 +325,21 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     const long long ntiles = (a.n + 15) / 16;
     float *const st = stash + wave_g * (long long)(NH * LAYER_STASH);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(st, 0, NH * LAYER_STASH * 4, 0x00020000);
-    float *const stage = lds + L.stage + wv * NT * STAGE_TILE;
+    float *const stage = lds + L.stage + wv * STG * STAGE_TILE;
     float *const gs = lds + L.gs;
     const float *const io = lds + L.io;
     // compact gradient block of Linear layer l < n_lin-1: bias first, then (hidden layers) tail rows / cols
     auto gblock = [&](int l) { return gs + (l == 0 ? 2 * W : L.gs_hid + (l - 1) * L.gs_hid_stride); };
+    // Where the small gradient entries are accumulated: the compact LDS block, or (WGLOBAL) this
+    // workgroup's slab in parameter order.  Same index arithmetic either way except the tail-column stride.
+    float *const slabp = (MODE != MODE_FWD) ? a.slab + (long long)blockIdx.x * (d.P + 2) : nullptr;
+    auto p_b = [&](int l) { return WGLOBAL ? slabp + d.boff[l] : gblock(l); };                      // [n]
+    auto p_tr = [&](int l) { return WGLOBAL ? slabp + d.woff[l] + NM * W : gblock(l) + W; };        // [e*W + i]
+    auto p_tc = [&](int l) { return WGLOBAL ? slabp + d.woff[l] + NM : gblock(l) + W + R * W; };    // [o*TCS + e]
+    constexpr int TCS = WGLOBAL ? W : (R > 0 ? R : 1);
+    float *const p_wout = WGLOBAL ? slabp + d.woff[d.n_lin - 1] : gs + L.gs_out;                    // [o*W + n]
+    float *const p_bout = WGLOBAL ? slabp + d.boff[d.n_lin - 1] : gs + L.gs_out + d.nout * W;       // [o]
+    float *const p_w0 = WGLOBAL ? slabp + d.woff[0] : gs;                                           // [2n + c]
     // per-lane byte offsets into the stash:
     // Lane-derived indices and per-lane byte offsets into the stash.  They are re-derived from an opaque
     // copy of the lane id at the start of every phase (PINN_REFRESH): left alone, the compiler hoists a
@@ -340,7 +362,6 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
     float *const xtp = lds + L.xt + wv * 128;
     float *const ztl = lds + L.ztl + wv * (R * ZTL_J * 16);
     float *const atl = lds + L.atl + wv * (R * ZTL_J * 16);
-    static_assert(J <= ZTL_J, "ZTL_J too small");
 
     for (long long tile = wave_g; tile < ntiles; tile += nwaves) {
         PINN_REFRESH();
@@ -678,7 +699,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
         for (int o = 0; o < MAXOUT; ++o)
             if (o < nout) {
                 const float bs = row_sum16(ub[o][0]);
-                if (lane == 0) PINN_ADD_S(&gs[L.gs_out + nout * W + o], bs);
+                if (lane == 0) PINN_ADD_S(&p_bout[o], bs);
             }
 
         // ---- top tanh layer (NH-1): A/At hold its pre-activations z; y is recomputed, its adjoint is the
@@ -686,7 +707,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
         //      A/At: z -> Zb. ----
         {
             const int hl = NH - 1;
-            float *gbias = gblock(hl);
+            float *gbias = p_b(hl);
             PINN_AT_PARK();
             PINN_SB();
 #pragma unroll
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                                 yb[j] = fmaf(wo, ub[o][j], yb[j]);
                             }
                             v = row_sum16(v);
-                            if (p == 0 && n < W) PINN_ADD_S(&gs[L.gs_out + o * W + n], v);
+                            if (p == 0 && n < W) PINN_ADD_S(&p_wout[o * W + n], v);
                         }
                     tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
 #pragma unroll
@@ -739,7 +760,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                                 yb[j] = fmaf(wo, ub[o][j], yb[j]);
                             }
                             v = row_sum16(v);
-                            if (lane == 0) PINN_ADD_S(&gs[L.gs_out + o * W + NM + e], v);
+                            if (lane == 0) PINN_ADD_S(&p_wout[o * W + NM + e], v);
                         }
                     tanh_jet_bwd<K, KT>(At[e], y, w, yb, zb);
 #pragma unroll
@@ -760,9 +781,9 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             // on entry A/At = Zb (adjoint of z_l);  Linear layer l maps y_{l-1} -> z_l
             const float *img = lds + L.hh + (l - 1) * C::HH;
             const int yprev = (l - 1) * LAYER_STASH + ZY;
-            float *gtc = gblock(l) + W + R * W;                                   // tail columns of Wb_l: [o][e]
-            float *gtr = gblock(l) + W;                                           // tail rows of Wb_l: [e][i]
-            float *wim = lds + L.wimg + (l - 1) * (NT * NT * TILE);              // main block of Wb_l
+            float *gtc = p_tc(l);                                                 // tail columns of Wb_l: [o*TCS + e]
+            float *gtr = p_tr(l);                                                 // tail rows of Wb_l: [e*W + i]
+            float *wim = lds + L.wimg + (l - 1) * (NT * NT * TILE);              // main block of Wb_l (LDS images)
 
             // Phase A: Wb[o][i] += sum_{p,k} Zb_k[o][p] * Y_k[i][p]   (reduction over points)
             {
@@ -803,30 +824,50 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
                             for (int s = 0; s < 4; ++s) bop[nx][Ti][s] = sb_load1(srs, vyn, yprev + (Ti * J + j + 1) * TILE + s * 16);
                     }
                     // A operand: Zb through the staging image [point][neuron] -> lane (m = p, kk = q) reads
-                    // Zb[16To + m][point 4kk + s]
+                    // Zb[16To + m][point 4kk + s]; STG tiles per pass (all NT unless LDS is short)
 #pragma unroll
-                    for (int To = 0; To < NT; ++To) *(f32x4 *)&stage[To * STAGE_TILE + p * STAGE_ROW + 4 * q] = A[To][j];
-                    PINN_LDS_FENCE();
-                    float aop[NT][4];
+                    for (int g0 = 0; g0 < NT; g0 += STG) {
 #pragma unroll
-                    for (int To = 0; To < NT; ++To)
+                        for (int t = 0; t < STG; ++t)
+                            if (g0 + t < NT) *(f32x4 *)&stage[t * STAGE_TILE + p * STAGE_ROW + 4 * q] = A[g0 + t][j];
+                        PINN_LDS_FENCE();
+                        float aop[STG][4];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) aop[To][s] = stage[To * STAGE_TILE + (4 * q + s) * STAGE_ROW + p];
+                        for (int t = 0; t < STG; ++t)
 #pragma unroll
-                    for (int To = 0; To < NT; ++To)
+                            for (int s = 0; s < 4; ++s) aop[t][s] = stage[t * STAGE_TILE + (4 * q + s) * STAGE_ROW + p];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) pin(aop[To][s]);
-                    PINN_SB();
+                        for (int t = 0; t < STG; ++t)
 #pragma unroll
-                    for (int To = 0; To < NT; ++To)
+                            for (int s = 0; s < 4; ++s) pin(aop[t][s]);
+                        PINN_SB();
 #pragma unroll
-                        for (int Ti = 0; Ti < NT; ++Ti)
+                        for (int t = 0; t < STG; ++t)
+                            if (g0 + t < NT) {
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) wacc[To][Ti] = mfma4(aop[To][s], bop[c][Ti][s], wacc[To][Ti]);
+                                for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s)
+                                        wacc[g0 + t][Ti] = mfma4(aop[t][s], bop[c][Ti][s], wacc[g0 + t][Ti]);
+                            }
+                        if (g0 + STG < NT) PINN_JB();
+                    }
                     PINN_JB();
                 }
                 // accumulator (To,Ti): lane (i = p, q) register r holds Wb[16To + 4q + r][16Ti + p]
-                if (!PINN_ABL_WACC || rt_false) {
+                if (WGLOBAL) {
+                    if (!PINN_ABL_WACC || rt_false) {
+                        float *gm = slabp + d.woff[l] + 4 * q * W + p;
+#pragma unroll
+                        for (int To = 0; To < NT; ++To)
+#pragma unroll
+                            for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (TAIL || (16 * To + 4 * q + r < W && 16 * Ti + p < W))
+                                        unsafeAtomicAdd(&gm[(16 * To + r) * W + 16 * Ti], wacc[To][Ti][r]);
+                    }
+                } else if (!PINN_ABL_WACC || rt_false) {
                     int *lk = (int *)(lds + L.locks) + (l - 1);
                     lds_lock(lk, lane);
 #pragma unroll
@@ -863,7 +904,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
 #pragma unroll
                                 for (int j = 0; j < J; ++j) v = fmaf(A[To][j][r], yp[j], v);
                                 v = row_sum16(v);
-                                if (p == 0) PINN_ADD_S(&gtc[(16 * To + 4 * q + r) * R + e], v);
+                                if (p == 0) PINN_ADD_S(&gtc[(16 * To + 4 * q + r) * TCS + e], v);
                             }
                     }
                 }
@@ -954,7 +995,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             PINN_REFRESH();
             const int hl = l - 1;
             const int zs = hl * LAYER_STASH;
-            float *gbias = gblock(hl);
+            float *gbias = p_b(hl);
             if (hl == 0) PINN_XT_FETCH();
             // z comes back from the stash neuron by neuron, PINN_ZPF neurons ahead of its use (one wave has
             // only one other wave on its SIMD to hide the load latency behind); y and w are recomputed.
@@ -1051,7 +1092,7 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
         PINN_REFRESH();
         PINN_XT_FETCH();
         {
-            float *gw0 = gs;
+            float *gw0 = p_w0;
 #pragma unroll
             for (int T = 0; T < NT; ++T)
 #pragma unroll
@@ -1095,34 +1136,39 @@ __global__ __launch_bounds__(MFMA_BLOCK, 1) void k_mfma(KDesc d, CallArgs a, flo
             }
         }
         __syncthreads();
-        // parameter order out of the compact block and the accumulator images
-        float *slab = a.slab + (long long)blockIdx.x * (P + 2);
-        for (int i = tid; i < P + 2; i += MFMA_BLOCK) {
-            float v;
-            if (i >= P) {
-                v = gs[L.gs_loss + (i - P)];
-            } else {
-                int l = 0;
-                while (l + 1 < n_lin && i >= d.woff[l + 1]) ++l;
-                const int fi = d.widths[l], fo = d.widths[l + 1];
-                const int rel = i - d.woff[l];
-                if (rel >= fi * fo) {                       // bias
-                    const int n = rel - fi * fo;
-                    v = (l == n_lin - 1) ? gs[L.gs_out + nout * W + n] : gblock(l)[n];
+        if (WGLOBAL) {
+            // the gradient went to the slab directly (hardware atomics); only the loss sums are in LDS
+            if (tid < 2) slabp[P + tid] = gs[L.gs_loss + tid];
+        } else {
+            // parameter order out of the compact block and the accumulator images
+            float *slab = a.slab + (long long)blockIdx.x * (P + 2);
+            for (int i = tid; i < P + 2; i += MFMA_BLOCK) {
+                float v;
+                if (i >= P) {
+                    v = gs[L.gs_loss + (i - P)];
                 } else {
-                    const int o = rel / fi, c = rel - o * fi;
-                    if (l == 0) v = gs[rel];
-                    else if (l == n_lin - 1) v = gs[L.gs_out + rel];
-                    else if (o >= NM) v = gblock(l)[W + (o - NM) * W + c];
-                    else if (c >= NM) v = gblock(l)[W + R * W + o * R + (c - NM)];
-                    else {
-                        // accumulator (To,Ti): lane (p, q) register r holds Wb[16To + 4q + r][16Ti + p]
-                        const int To = o >> 4, q4 = (o & 15) >> 2, r = o & 3, Ti = c >> 4, pp = c & 15;
-                        v = lds[L.wimg + (((l - 1) * NT + To) * NT + Ti) * TILE + (q4 * 16 + pp) * 4 + r];
+                    int l = 0;
+                    while (l + 1 < n_lin && i >= d.woff[l + 1]) ++l;
+                    const int fi = d.widths[l], fo = d.widths[l + 1];
+                    const int rel = i - d.woff[l];
+                    if (rel >= fi * fo) {                       // bias
+                        const int n = rel - fi * fo;
+                        v = (l == n_lin - 1) ? gs[L.gs_out + nout * W + n] : gblock(l)[n];
+                    } else {
+                        const int o = rel / fi, c = rel - o * fi;
+                        if (l == 0) v = gs[rel];
+                        else if (l == n_lin - 1) v = gs[L.gs_out + rel];
+                        else if (o >= NM) v = gblock(l)[W + (o - NM) * W + c];
+                        else if (c >= NM) v = gblock(l)[W + R * W + o * R + (c - NM)];
+                        else {
+                            // accumulator (To,Ti): lane (p, q) register r holds Wb[16To + 4q + r][16Ti + p]
+                            const int To = o >> 4, q4 = (o & 15) >> 2, r = o & 3, Ti = c >> 4, pp = c & 15;
+                            v = lds[L.wimg + (((l - 1) * NT + To) * NT + Ti) * TILE + (q4 * 16 + pp) * 4 + r];
+                        }
                     }
                 }
+                slab[i] = v;
             }
-            slab[i] = v;
         }
     }
 }
@@ -1140,12 +1186,32 @@ struct MfmaPlan {
 #ifdef PINN_DEV_KDV7_ONLY
 #define PINN_MFMA_WIDTHS(X) X(50)
 #else
-#define PINN_MFMA_WIDTHS(X) X(50) X(64)
+#define PINN_MFMA_WIDTHS(X) X(50) X(64) X(100)
 #endif
 
-template <int W> size_t mfma_lds_bytes(const KDesc &kd) { return (size_t)mfma_layout<W>(kd).total * sizeof(float); }
+template <int W> size_t mfma_lds_bytes(const KDesc &kd, int J) { return (size_t)mfma_layout<W>(kd, J).total * sizeof(float); }
 
-inline bool mfma_supported(const KDesc &kd)
+// waves per workgroup / whether the kernel accumulates straight into the (pre-zeroed) slab
+inline int mfma_waves(const KDesc &kd)
+{
+    switch (kd.widths[1]) {
+#define X(w) case w: return WidthCfg<w>::WAVES;
+        PINN_MFMA_WIDTHS(X)
+#undef X
+    default: return MFMA_MAX_WAVES;
+    }
+}
+inline bool mfma_wglobal(const KDesc &kd)
+{
+    switch (kd.widths[1]) {
+#define X(w) case w: return WidthCfg<w>::WGLOBAL;
+        PINN_MFMA_WIDTHS(X)
+#undef X
+    default: return false;
+    }
+}
+
+inline bool mfma_supported(const KDesc &kd, int J)
 {
     if (kd.n_lin < 2) return false;
     const int W = kd.widths[1];
@@ -1153,7 +1219,7 @@ inline bool mfma_supported(const KDesc &kd)
         if (kd.widths[l] != W) return false;
     size_t lds = 0;
     switch (W) {
-#define X(w) case w: lds = mfma_lds_bytes<w>(kd); break;
+#define X(w) case w: lds = mfma_lds_bytes<w>(kd, J); break;
         PINN_MFMA_WIDTHS(X)
 #undef X
     default: return false;
@@ -1196,7 +1262,7 @@ inline void mfma_plan_destroy(MfmaPlan &pl)
 template <int EQ, int W, int MODE>
 int launch_mfma_t(MfmaPlan &pl, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
-    const size_t ldsb = mfma_lds_bytes<W>(kd);
+    const size_t ldsb = mfma_lds_bytes<W>(kd, EqTraits<EQ>::K + 1 + EqTraits<EQ>::KT);
     auto kern = k_mfma<EQ, W, MODE>;
     if (ldsb > 48 * 1024) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) {
@@ -1204,7 +1270,7 @@ int launch_mfma_t(MfmaPlan &pl, const KDesc &kd, const CallArgs &a, int grid, hi
             return -3;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MFMA_BLOCK), ldsb, st, kd, a, pl.stash);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WidthCfg<W>::BLOCK), ldsb, st, kd, a, pl.stash);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

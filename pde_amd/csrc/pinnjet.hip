@@ -152,16 +152,20 @@ int run_mfma(MfmaPlan &pl, const KDesc &kd, int eq, int mode, CallArgs a, float 
     if (eq_orders(eq, kd.nout, &K, &KT, &nf)) return PINN_ERR_INVALID_DESC;
     const int J = K + 1 + KT;
     const long long ntiles = (a.n + 15) / 16;
-    const long long need_blocks = (ntiles + MFMA_WAVES - 1) / MFMA_WAVES;
+    const int waves = mfma_waves(kd);
+    const long long need_blocks = (ntiles + waves - 1) / waves;
     const int grid = (int)(need_blocks < pl.grid ? need_blocks : pl.grid);
     int rc;
     if (mode != MODE_FWD) {
         const size_t per_wave = mfma_stash_floats(kd, J) * sizeof(float);
-        rc = ensure(&pl.stash, &pl.stash_bytes, per_wave * grid * MFMA_WAVES);
+        rc = ensure(&pl.stash, &pl.stash_bytes, per_wave * grid * waves);
         if (rc) return rc;
-        rc = ensure(&pl.slab, &pl.slab_bytes, (size_t)grid * (kd.P + 2) * sizeof(float));
+        const size_t slab_bytes = (size_t)grid * (kd.P + 2) * sizeof(float);
+        rc = ensure(&pl.slab, &pl.slab_bytes, slab_bytes);
         if (rc) return rc;
         a.slab = pl.slab;
+        // wide layers accumulate into their slab with atomics: it has to start at zero
+        if (mfma_wglobal(kd) && hipMemsetAsync(pl.slab, 0, slab_bytes, st) != hipSuccess) return PINN_ERR_HIP;
     }
     switch (mode) {
     case MODE_FWD:  rc = launch_mfma_eq<MODE_FWD>(pl, eq, kd, a, grid, st); break;
@@ -239,7 +243,7 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     for (int l = 1; l < desc->n_lin; ++l) uniform = uniform && desc->widths[l] == W;
     int kernel = desc->kernel;
 #ifdef PINN_WITH_MFMA
-    const bool mfma_ok = uniform && mfma_supported(kd);
+    const bool mfma_ok = uniform && mfma_supported(kd, K + 1 + KT);
 #else
     const bool mfma_ok = false;
 #endif
