@@ -161,6 +161,48 @@ def test_ragged_sizes_against_oracle(name, kname, kernel):
         assert rel(grad.cpu().numpy(), gref) < 1e-5, n
 
 
+@pytest.mark.parametrize("eq,width,depth", [
+    ("kdv7_3sol", 50, 1), ("kdv7_3sol", 50, 2), ("kdv7_3sol", 50, 6),     # 1 / 2 / 6 tanh layers (bc nets use 5-6)
+    ("ch", 64, 1), ("ch", 64, 2), ("ch", 64, 6),
+    ("gnss", 100, 1), ("gnss", 100, 2), ("gnss", 100, 4), ("gnss", 50, 5), ("burgers", 100, 3),
+])
+def test_mfma_depths_against_oracle(eq, width, depth):
+    """The MFMA kernels treat the first and the last tanh layer specially (z recomputed / z kept in
+    registers): nets where these coincide or touch, both workgroup shapes (widths <= 64 and 100),
+    seeded xavier weights, vs the fp64 oracle.  Tolerance 1e-5 (1e-4 for the 7th-order case)."""
+    nout = 2 if eq == "gnss" else 1
+    layers = [2] + [width] * depth + [nout]
+    lb, ub = np.array([-5.0, -1.0]), np.array([5.0, 1.0])
+    rng = np.random.default_rng(width * 10 + depth)
+    theta = []
+    for i in range(len(layers) - 1):
+        fi, fo = layers[i], layers[i + 1]
+        theta.append(rng.standard_normal(fi * fo) * np.sqrt(2.0 / (fi + fo)))
+        theta.append(0.1 * rng.standard_normal(fo))
+    theta = np.concatenate(theta).astype(np.float32)
+    try:
+        eng = NativeEngine(equations.get(eq), layers, lb.astype(np.float32), ub.astype(np.float32), dev(), kernel=KERNEL_MFMA)
+    except NativeError as ex:
+        if "unsupported" in str(ex):
+            pytest.skip(str(ex))
+        raise
+    o = Oracle(eq, layers, lb, ub)
+    tol = 1e-4 if eq.startswith("kdv7") else 1e-5
+    for n in (37, 4099):
+        X = (lb + (ub - lb) * rng.random((n, 2))).astype(np.float32)
+        ls = torch.zeros(eng.nf, device=dev())
+        grad = torch.zeros(eng.P, device=dev())
+        eng.loss_grad(cu(theta), cu(X[:, 0]), cu(X[:, 1]), 1.0 / n, ls, grad)
+        f = eng.residual_fwd(cu(theta), cu(X[:, 0]), cu(X[:, 1])).cpu().numpy()
+        der64, f64 = o.forward(theta.astype(np.float64), X[:, 0], X[:, 1])
+        lref, gref = o.loss_grad(theta.astype(np.float64), X[:, 0], X[:, 1], scale=1.0 / n)
+        torch.cuda.synchronize()
+        scale = max(np.linalg.norm(der64[:, :, j]) for j in range(der64.shape[2]))
+        assert np.linalg.norm(f.reshape(f64.shape) - f64) <= tol * scale, (n, "f")
+        assert rel(ls.cpu().numpy(), lref) < tol, (n, "loss")
+        assert rel(grad.cpu().numpy(), gref) < tol, (n, "grad")
+
+
 @pytest.mark.parametrize("kname,kernel", KINDS)
 def test_full_size_properties(kname, kernel):
     """BASELINE config sizes are too big for the oracle; use size-independent
