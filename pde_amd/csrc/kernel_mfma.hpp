@@ -1249,6 +1249,11 @@ inline size_t mfma_stash_floats(const KDesc &kd, int J)
 inline int mfma_plan_create(MfmaPlan &pl, const KDesc &, int n_cu)
 {
     pl.grid = n_cu;
+    // development knob: fewer workgroups (e.g. to shrink the stash footprint in experiments)
+    if (const char *g = getenv("PINN_MFMA_GRID")) {
+        const int v = atoi(g);
+        if (v > 0 && v < n_cu) pl.grid = v;
+    }
     return 0;
 }
 

@@ -1,6 +1,7 @@
 // C-ABI of the PINN collocation engine (include/pinnjet.h) and kernel dispatch.
 #include <hip/hip_runtime.h>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/pinnjet.h"
