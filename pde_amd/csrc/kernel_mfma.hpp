@@ -64,14 +64,16 @@ template <int W> struct WidthCfg {
     // Workgroup shape.  Up to width 64 the weights, the weight-gradient images and the staging area of
     // eight waves fit in LDS together: two waves per SIMD, <= 256 registers each.  Wider layers
     // (GNSS, width 100 = 96 + 4) fill LDS with the weights alone: four waves (one per SIMD, 512
-    // registers: the 36 weight-gradient accumulator tiles of a layer live in AGPRs), Zb staged STG
-    // tiles at a time, and ALL gradient accumulation goes to the workgroup's global slab with
-    // hardware float atomics (L2-resident: 123 KB per workgroup) instead of LDS.
+    // registers: the 36 weight-gradient accumulator tiles of a layer live in AGPRs, nothing needs
+    // parking in LDS), Zb staged STG tiles at a time, and the weight-gradient tiles go to the
+    // workgroup's global slab with hardware float atomics (L2: 123 KB per workgroup) instead of LDS
+    // images; the small entries (biases, tails) stay in the compact LDS block.
     static constexpr bool WIDE = W > 64;
     static constexpr int WAVES = WIDE ? 4 : PINN_MFMA_BLOCK / 64;
     static constexpr int BLOCK = 64 * WAVES;
     static constexpr bool WGLOBAL = WIDE;
-    static constexpr int STG = WIDE ? (NT + 1) / 2 : NT;       // Zb tiles staged per pass of the weight-gradient GEMM
+    static constexpr bool PARK = !WIDE;                        // park registers in LDS around the neuron loops
+    static constexpr int STG = WIDE ? (NT + 2) / 3 : NT;       // Zb tiles staged per pass of the weight-gradient GEMM
     static constexpr int S = NM + 4;                           // row stride of the main weight image
     // one hidden->hidden layer image in LDS (floats)
     static constexpr int O_BIAS = NM * S;          // [NM]
@@ -119,15 +121,14 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     L.gs_hid_stride = W + C::R * W + C::NM * C::R;
     L.gs_out = L.gs_hid + (d.n_lin - 2) * L.gs_hid_stride;
     L.gs_loss = L.gs_out + d.nout * W + d.nout;
-    if (C::WGLOBAL) L.gs_loss = 0;                 // only the loss sums stay in LDS
     L.gs_size = ((L.gs_loss + 2 + 3) / 4) * 4;
     off += L.gs_size;
     L.wimg = off; off += C::WGLOBAL ? 0 : (d.n_lin - 2) * C::NT * C::NT * 256;
     L.locks = off; off += ((d.n_lin - 2 + 3) / 4) * 4 + 4;
     L.stage = off; off += C::WAVES * C::STG * STAGE_TILE;
-    L.xt = off; off += C::WAVES * 128;
+    L.xt = off; off += C::PARK ? C::WAVES * 128 : 0;
     L.ztl = off; off += C::WAVES * C::R * J * 16;
-    L.atl = off; off += C::WAVES * C::R * J * 16;
+    L.atl = off; off += C::PARK ? C::WAVES * C::R * J * 16 : 0;
     L.total = off;
     return L;
 }
@@ -155,7 +156,7 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
 #ifndef PINN_ZPF
 #define PINN_ZPF 2           // reverse sweep: z of a neuron is requested this many neurons ahead
 #endif
-#define PINN_ADD_S(addr, v) do { if (!PINN_ABL_SATOM || rt_false) { if (WGLOBAL) unsafeAtomicAdd(addr, v); else atomicAdd(addr, v); } } while (0)
+#define PINN_ADD_S(addr, v) do { if (!PINN_ABL_SATOM || rt_false) atomicAdd(addr, v); } while (0)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
@@ -330,17 +331,15 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
     const float *const io = lds + L.io;
     // compact gradient block of Linear layer l < n_lin-1: bias first, then (hidden layers) tail rows / cols
     auto gblock = [&](int l) { return gs + (l == 0 ? 2 * W : L.gs_hid + (l - 1) * L.gs_hid_stride); };
-    // Where the small gradient entries are accumulated: the compact LDS block, or (WGLOBAL) this
-    // workgroup's slab in parameter order.  Same index arithmetic either way except the tail-column stride.
+    // the small gradient entries (accumulated with few-lane LDS atomics)
     float *const slabp = (MODE != MODE_FWD) ? a.slab + (long long)blockIdx.x * (d.P + 2) : nullptr;
-    auto p_b = [&](int l) { return WGLOBAL ? slabp + d.boff[l] : gblock(l); };                      // [n]
-    auto p_tr = [&](int l) { return WGLOBAL ? slabp + d.woff[l] + NM * W : gblock(l) + W; };        // [e*W + i]
-    auto p_tc = [&](int l) { return WGLOBAL ? slabp + d.woff[l] + NM : gblock(l) + W + R * W; };    // [o*TCS + e]
-    constexpr int TCS = WGLOBAL ? W : (R > 0 ? R : 1);
-    float *const p_wout = WGLOBAL ? slabp + d.woff[d.n_lin - 1] : gs + L.gs_out;                    // [o*W + n]
-    float *const p_bout = WGLOBAL ? slabp + d.boff[d.n_lin - 1] : gs + L.gs_out + d.nout * W;       // [o]
-    float *const p_w0 = WGLOBAL ? slabp + d.woff[0] : gs;                                           // [2n + c]
-    // per-lane byte offsets into the stash:
+    auto p_b = [&](int l) { return gblock(l); };                      // bias of Linear layer l < n_lin-1: [n]
+    auto p_tr = [&](int l) { return gblock(l) + W; };                 // tail rows of Wb_l: [e*W + i]
+    auto p_tc = [&](int l) { return gblock(l) + W + R * W; };         // tail columns of Wb_l: [o*TCS + e]
+    constexpr int TCS = R > 0 ? R : 1;
+    float *const p_wout = gs + L.gs_out;                              // [o*W + n]
+    float *const p_bout = gs + L.gs_out + d.nout * W;                 // [o]
+    float *const p_w0 = gs;                                           // [2n + c]
     // Lane-derived indices and per-lane byte offsets into the stash.  They are re-derived from an opaque
     // copy of the lane id at the start of every phase (PINN_REFRESH): left alone, the compiler hoists a
     // few dozen loop-invariant per-lane addresses out of the tile loop, spills them, and every reload
@@ -373,8 +372,8 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
         // spilled to scratch by the register allocator
         float hx = 2.0f * (xv - d.lbx) / dxr - 1.0f;
         float ht = 2.0f * (tv - d.lbt) / dtr - 1.0f;
-#define PINN_XT_PARK() do { xtp[lane] = hx; xtp[64 + lane] = ht; } while (0)
-#define PINN_XT_FETCH() do { asm volatile("" ::: "memory"); hx = xtp[lane]; ht = xtp[64 + lane]; } while (0)
+#define PINN_XT_PARK() do { if (C::PARK) { xtp[lane] = hx; xtp[64 + lane] = ht; } } while (0)
+#define PINN_XT_FETCH() do { if (C::PARK) { asm volatile("" ::: "memory"); hx = xtp[lane]; ht = xtp[64 + lane]; } } while (0)
         if (MODE != MODE_FWD) PINN_XT_PARK();
 
         // The one register-resident set: activations on the way up, adjoints on the way down.
@@ -382,9 +381,9 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
         float At[RR][J];       // tail neurons (same value in all four lane quads)
         // The reverse sweep's per-neuron loops need every register they can get: the tail set is parked
         // in LDS around them.
-#define PINN_AT_PARK() do { if (TAIL) { if (q == 0) { _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
+#define PINN_AT_PARK() do { if (TAIL && C::PARK) { if (q == 0) { _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
             atl[(e * ZTL_J + j) * 16 + p] = At[e][j]; } } } while (0)
-#define PINN_AT_FETCH() do { if (TAIL) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
+#define PINN_AT_FETCH() do { if (TAIL && C::PARK) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
             At[e][j] = atl[(e * ZTL_J + j) * 16 + p]; } } while (0)
 
         // first-layer pre-activation jets (also recomputed in the reverse sweep: they are affine in (x,t),
@@ -857,7 +856,10 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                 // accumulator (To,Ti): lane (i = p, q) register r holds Wb[16To + 4q + r][16Ti + p]
                 if (WGLOBAL) {
                     if (!PINN_ABL_WACC || rt_false) {
-                        float *gm = slabp + d.woff[l] + 4 * q * W + p;
+                        // buffer atomics: one per-lane offset VGPR, everything else scalar
+                        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + 2) * 4, 0x00020000);
+                        const int gvoff = (4 * q * W + p) * 4;
+                        const int gsoff = d.woff[l] * 4;
 #pragma unroll
                         for (int To = 0; To < NT; ++To)
 #pragma unroll
@@ -865,7 +867,8 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
 #pragma unroll
                                 for (int r = 0; r < 4; ++r)
                                     if (TAIL || (16 * To + 4 * q + r < W && 16 * Ti + p < W))
-                                        unsafeAtomicAdd(&gm[(16 * To + r) * W + 16 * Ti], wacc[To][Ti][r]);
+                                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wacc[To][Ti][r], grs, gvoff,
+                                                                                        gsoff + ((16 * To + r) * W + 16 * Ti) * 4, 0);
                     }
                 } else if (!PINN_ABL_WACC || rt_false) {
                     int *lk = (int *)(lds + L.locks) + (l - 1);
@@ -1136,10 +1139,7 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
             }
         }
         __syncthreads();
-        if (WGLOBAL) {
-            // the gradient went to the slab directly (hardware atomics); only the loss sums are in LDS
-            if (tid < 2) slabp[P + tid] = gs[L.gs_loss + tid];
-        } else {
+        {
             // parameter order out of the compact block and the accumulator images
             float *slab = a.slab + (long long)blockIdx.x * (P + 2);
             for (int i = tid; i < P + 2; i += MFMA_BLOCK) {
@@ -1160,6 +1160,7 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                         else if (l == n_lin - 1) v = gs[L.gs_out + rel];
                         else if (o >= NM) v = gblock(l)[W + (o - NM) * W + c];
                         else if (c >= NM) v = gblock(l)[W + R * W + o * R + (c - NM)];
+                        else if (WGLOBAL) continue;      // went to the (pre-zeroed) slab directly, by hardware atomics
                         else {
                             // accumulator (To,Ti): lane (p, q) register r holds Wb[16To + 4q + r][16Ti + p]
                             const int To = o >> 4, q4 = (o & 15) >> 2, r = o & 3, Ti = c >> 4, pp = c & 15;
@@ -1183,8 +1184,10 @@ struct MfmaPlan {
 };
 
 // hidden widths with an MFMA instantiation; anything else runs on the VALU path
-#ifdef PINN_DEV_KDV7_ONLY
+#if defined(PINN_DEV_KDV7_ONLY)
 #define PINN_MFMA_WIDTHS(X) X(50)
+#elif defined(PINN_DEV_GNSS100_ONLY)
+#define PINN_MFMA_WIDTHS(X) X(100)
 #else
 #define PINN_MFMA_WIDTHS(X) X(50) X(64) X(100)
 #endif
@@ -1294,6 +1297,9 @@ template <int MODE>
 int launch_mfma_eq(MfmaPlan &pl, int eq, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
     switch (eq) {
+#if defined(PINN_DEV_GNSS100_ONLY)
+    case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(pl, kd, a, grid, st);
+#else
 #ifndef PINN_DEV_KDV7_ONLY
     case EQ_NONE:    return launch_mfma_w<EQ_NONE, MODE>(pl, kd, a, grid, st);
     case EQ_BURGERS: return launch_mfma_w<EQ_BURGERS, MODE>(pl, kd, a, grid, st);
@@ -1302,6 +1308,7 @@ int launch_mfma_eq(MfmaPlan &pl, int eq, const KDesc &kd, const CallArgs &a, int
     case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(pl, kd, a, grid, st);
 #endif
     case EQ_KDV7:    return launch_mfma_w<EQ_KDV7, MODE>(pl, kd, a, grid, st);
+#endif
     default: return -1;
     }
 }

@@ -1,9 +1,10 @@
 #!/bin/bash
-# run every build_dev/lib_*.so (or the names given) through tools/prof_target.py; one line per variant
+# run build_dev/lib_<name>.so (all, or the names given) through tools/prof_target.py; one line per variant
+# WORKLOAD=gnss tools/run_variants.sh ...   selects the bench workload
 cd "$(dirname "$0")/.."
 names="$@"
 [ -z "$names" ] && names=$(ls build_dev/lib_*.so | sed 's/.*lib_//; s/\.so//')
 for n in $names; do
-  r=$(timeout -k 10 120 python3 tools/prof_target.py --iters 3 --lib build_dev/lib_$n.so 2>&1 | tail -1) || { echo "$n: FAILED $r"; exit 1; }
+  r=$(timeout -k 10 120 python3 tools/prof_target.py --iters 3 --workload ${WORKLOAD:-kdv7} --lib build_dev/lib_$n.so 2>&1 | tail -1) || { echo "$n: FAILED $r"; exit 1; }
   echo "$n: $r"
 done
