@@ -1189,7 +1189,7 @@ struct MfmaPlan {
 #elif defined(PINN_DEV_GNSS100_ONLY)
 #define PINN_MFMA_WIDTHS(X) X(100)
 #else
-#define PINN_MFMA_WIDTHS(X) X(50) X(64) X(100)
+#define PINN_MFMA_WIDTHS(X) X(20) X(50) X(64) X(100)
 #endif
 
 template <int W> size_t mfma_lds_bytes(const KDesc &kd, int J) { return (size_t)mfma_layout<W>(kd, J).total * sizeof(float); }

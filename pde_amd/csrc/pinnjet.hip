@@ -238,7 +238,7 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) { (void)hipGetLastError(); delete h; return PINN_ERR_HIP; }
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    // kernel family: MFMA once the hidden width is >= 32 (uniform hidden widths only)
+    // kernel family: MFMA whenever an instantiation covers the (uniform) hidden width and fits LDS
     bool uniform = desc->n_lin >= 2;
     const int W = desc->widths[1];
     for (int l = 1; l < desc->n_lin; ++l) uniform = uniform && desc->widths[l] == W;
@@ -248,7 +248,7 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
 #else
     const bool mfma_ok = false;
 #endif
-    if (kernel == PINN_KERNEL_AUTO) kernel = (mfma_ok && W >= 32) ? PINN_KERNEL_MFMA : PINN_KERNEL_VALU;
+    if (kernel == PINN_KERNEL_AUTO) kernel = mfma_ok ? PINN_KERNEL_MFMA : PINN_KERNEL_VALU;
     if (kernel == PINN_KERNEL_MFMA && !mfma_ok) { delete h; return PINN_ERR_UNSUPPORTED; }
     if (kernel != PINN_KERNEL_MFMA && kernel != PINN_KERNEL_VALU) { delete h; return PINN_ERR_INVALID_DESC; }
     if (kernel == PINN_KERNEL_VALU && (size_t)(kd.P + 2) * sizeof(float) > 160 * 1024) { delete h; return PINN_ERR_UNSUPPORTED; }

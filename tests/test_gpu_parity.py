@@ -165,6 +165,7 @@ def test_ragged_sizes_against_oracle(name, kname, kernel):
     ("kdv7_3sol", 50, 1), ("kdv7_3sol", 50, 2), ("kdv7_3sol", 50, 6),     # 1 / 2 / 6 tanh layers (bc nets use 5-6)
     ("ch", 64, 1), ("ch", 64, 2), ("ch", 64, 6),
     ("gnss", 100, 1), ("gnss", 100, 2), ("gnss", 100, 4), ("gnss", 50, 5), ("burgers", 100, 3),
+    ("burgers", 20, 1), ("burgers", 20, 8), ("kdv5", 20, 3),                 # width 20 = one MFMA tile + 4 tail neurons
 ])
 def test_mfma_depths_against_oracle(eq, width, depth):
     """The MFMA kernels treat the first and the last tanh layer specially (z recomputed / z kept in
