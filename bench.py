@@ -18,6 +18,7 @@ Besides the contract fields the JSON line carries
   train_steps_per_s   full backward()+Adam.step() iterations/s (IC/BC terms included)
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -201,6 +202,7 @@ def main():
 
     # ---- full training step (IC/BC terms + Adam) ----
     train_sps = None
+    graph_info = None
     if args.train_steps > 0:
         model.iter = 1
         opt = torch.optim.Adam(model.dnn.parameters())
@@ -212,6 +214,15 @@ def main():
             opt.zero_grad(); model.backward(); opt.step()
         sync()
         train_sps = args.train_steps / (time.perf_counter() - t1)
+        # same iterations replayed from a captured HIP graph (single process only)
+        if world == 1:
+            model.use_hip_graph = True
+            model.iter = 1
+            with contextlib.redirect_stdout(sys.stderr):   # train() prints the reference's log lines
+                model.train(max(args.train_steps, 20) + 3, LBFGS_max_iter=0)   # 3 eager iterations + capture + replays
+            sync()
+            gs = getattr(model, "graph_stats", None)
+            graph_info = {"replays": gs["replays"], "train_steps_per_s": gs["replays"] / gs["seconds"]} if gs else None
 
     if rank == 0:
         line = {
@@ -232,6 +243,7 @@ def main():
                        "parallelism": "dp%d over collocation points" % world,
                        "kernel": {1: "valu", 2: "mfma"}[eng.kernel_kind]},
             "train_steps_per_s": train_sps,
+            "train_hip_graph": graph_info,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "kernel_ms": 1e3 * k_avg,

@@ -60,6 +60,7 @@ class PhysicsInformedNN:
     base_dir = os.getcwd()           # where model/ and log/ live (<script dir> in the reference)
     default_device = None            # None -> current CUDA device
     kernel = KERNEL_AUTO
+    use_hip_graph = False            # train(): replay the Adam phase from a captured HIP graph (single process)
     engine_factory = None            # test hook: callable(equation|None, layers, lb, ub, device) -> engine
 
     def __init__(self, layers, lb, ub, prev_model=None, process_group=None):
@@ -214,9 +215,9 @@ class PhysicsInformedNN:
             s = s + torch.mean(torch.square(pred[:, c:c + 1] - tgt))
         return s
 
-    def backward(self):
-        """Same loss composition as the reference's backward() (:97-120 and variants);
-        returns the 0-dim loss with `.grad` accumulated on dnn.parameters()."""
+    def _loss_terms(self):
+        """Loss composition of the reference's backward() (:97-120 and variants) + loss.backward().
+        Pure device work (no host sync): this is what train() captures into a HIP graph."""
         v = self.variant
         two = self.equation.nout == 2
         out0 = self.dnn(torch.cat([self.x0, self.t0], dim=1))
@@ -240,31 +241,44 @@ class PhysicsInformedNN:
         if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
             outp = self.dnn(self.X_prev)
             loss_prev = self._mse(outp, self.u_prev, self.v_prev) if two else self._mse(outp, self.u_prev)
-            if self.iter % 100 == 0:
-                print(f"Overlap loss: {loss_prev.item():.5e}")
 
         loss = loss0 + loss_b + loss_f
         if loss1 is not None:
             loss = loss + loss1
         loss = loss + loss_prev
         loss.backward()
+        return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev}
 
-        if self.iter % 100 == 0:
-            if v.style == "sw":
-                message = 'Iter: %d, Loss: %.5e, Loss0: %.5e, Loss_b: %.5e, Loss_f: %.5e, Loss_prev: %.5e' % (
-                    self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item(), float(loss_prev))
-            elif loss1 is not None:
-                message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_1: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
-                    self.iter, loss.item(), loss0.item(), loss1.item(), loss_b.item(), loss_f.item())
-            else:
-                message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
-                    self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item())
-            if self.logfilename is not None:
-                self.writer.write(message)
-            if self._is_rank0():
-                print(message)
+    def _log_terms(self, terms):
+        """The reference's every-100-iterations log line (the only host syncs of a closure)."""
+        if self.iter % 100 != 0:
+            return
+        v = self.variant
+        loss, loss0, loss_b, loss_f = terms["loss"], terms["loss0"], terms["loss_b"], terms["loss_f"]
+        loss1, loss_prev = terms["loss1"], terms["loss_prev"]
+        if v.style == "sw" and torch.is_tensor(loss_prev):
+            print(f"Overlap loss: {loss_prev.item():.5e}")
+        if v.style == "sw":
+            message = 'Iter: %d, Loss: %.5e, Loss0: %.5e, Loss_b: %.5e, Loss_f: %.5e, Loss_prev: %.5e' % (
+                self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item(), float(loss_prev))
+        elif loss1 is not None:
+            message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_1: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
+                self.iter, loss.item(), loss0.item(), loss1.item(), loss_b.item(), loss_f.item())
+        else:
+            message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
+                self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item())
+        if self.logfilename is not None:
+            self.writer.write(message)
+        if self._is_rank0():
+            print(message)
+
+    def backward(self):
+        """Same loss composition as the reference's backward() (:97-120 and variants);
+        returns the 0-dim loss with `.grad` accumulated on dnn.parameters()."""
+        terms = self._loss_terms()
+        self._log_terms(terms)
         self.iter += 1
-        return loss
+        return terms["loss"]
 
     def _is_rank0(self):
         if self.group is None:
@@ -294,7 +308,10 @@ class PhysicsInformedNN:
             self.writer = FileWriter(logfilename, self.base_dir)
             self.writer.write("Start Training:", mode='w')
         start_time = time.time()
-        for _ in range(nIter):
+        done = 0
+        if self.use_hip_graph and nIter > 16 and self.group is None and torch.device(self.device).type == "cuda":
+            done = self._train_adam_graph(nIter, params)
+        for _ in range(nIter - done):
             self.optimizer_Adam.zero_grad()
             self.backward()
             self.optimizer_Adam.step()
@@ -309,6 +326,54 @@ class PhysicsInformedNN:
             self.writer.write('Training time: %.4f' % (elapsed))
         if self._is_rank0():
             print('Training time: %.4f' % (elapsed))
+
+    def _train_adam_graph(self, nIter, params):
+        """the Adam phase without per-iteration host work.  One whole iteration
+        (zero_grad, the loss terms, loss.backward(), Adam(capturable).step()) is captured into a HIP
+        graph after a few eager iterations and replayed; the host only touches the device for the
+        reference's every-100-iterations log line.  Same kernels in the same order as the eager loop
+        (Adam's bias corrections are evaluated on the device in fp32 instead of in Python doubles).
+        Returns the number of iterations done; on any capture failure the caller continues eagerly."""
+        v = self.variant
+        kw = dict(capturable=True)
+        if v.optimizer == "adamw":
+            opt = torch.optim.AdamW(params, weight_decay=v.weight_decay, **kw)
+        else:
+            opt = torch.optim.Adam(params, **kw)
+        self.optimizer_Adam = opt
+        done = 0
+        try:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(3):                      # eager: allocates workspaces, initialises Adam state
+                    opt.zero_grad(set_to_none=True)
+                    self.backward()
+                    opt.step()
+                    done += 1
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                terms = self._loss_terms()
+                opt.step()
+        except Exception as ex:                         # noqa: BLE001 - any capture problem -> eager loop
+            print("HIP-graph capture of the training step failed (%s); continuing eagerly" % (ex,))
+            torch.cuda.synchronize(self.device)
+            self.optimizer_Adam = torch.optim.AdamW(params, weight_decay=v.weight_decay) if v.optimizer == "adamw" \
+                else torch.optim.Adam(params)
+            return done
+        t_rep, n_rep = time.time(), nIter - done
+        while done < nIter:
+            graph.replay()
+            self._log_terms(terms)
+            self.iter += 1
+            done += 1
+        torch.cuda.synchronize(self.device)
+        self.graph_stats = {"replays": n_rep, "seconds": time.time() - t_rep}
+        self._adam_graph = graph                        # keep the captured buffers alive with the model
+        return done
 
     # ------------------------------------------------------------------ io
     def load_model(self, filename):
