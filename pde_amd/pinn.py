@@ -220,11 +220,14 @@ class PhysicsInformedNN:
         Pure device work (no host sync): this is what train() captures into a HIP graph."""
         v = self.variant
         two = self.equation.nout == 2
-        out0 = self.dnn(torch.cat([self.x0, self.t0], dim=1))
+        # the three small data-term batches (IC, lower and upper boundary) go through net_u as ONE
+        # batch: one forward and one vjp launch instead of three each (same values per point)
+        n0, nb = self.x0.shape[0], self.x_lb.shape[0]
+        out_all = self.dnn(torch.cat([torch.cat([self.x0, self.t0], dim=1),
+                                      torch.cat([self.x_lb, self.tb], dim=1),
+                                      torch.cat([self.x_ub, self.tb], dim=1)], dim=0))
+        out0, out_lb, out_ub = out_all[:n0], out_all[n0:n0 + nb], out_all[n0 + nb:]
         loss0 = self._mse(out0, self.u0, self.v0) if two else self._mse(out0, self.u0)
-
-        out_lb = self.dnn(torch.cat([self.x_lb, self.tb], dim=1))
-        out_ub = self.dnn(torch.cat([self.x_ub, self.tb], dim=1))
         if v.bc == "dirichlet":
             loss_b = torch.mean(torch.square(out_lb)) + torch.mean(torch.square(out_ub))
         else:
