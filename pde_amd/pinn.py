@@ -263,7 +263,8 @@ class PhysicsInformedNN:
             print(f"Overlap loss: {loss_prev.item():.5e}")
         if v.style == "sw":
             message = 'Iter: %d, Loss: %.5e, Loss0: %.5e, Loss_b: %.5e, Loss_f: %.5e, Loss_prev: %.5e' % (
-                self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item(), float(loss_prev))
+                self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item(),
+                loss_prev.item() if torch.is_tensor(loss_prev) else float(loss_prev))
         elif loss1 is not None:
             message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_1: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
                 self.iter, loss.item(), loss0.item(), loss1.item(), loss_b.item(), loss_f.item())
