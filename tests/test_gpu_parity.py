@@ -331,3 +331,19 @@ def test_hip_graph_training_matches_eager():
     assert res[True][1] < res[True][0]
     assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
     assert rel(res[True][2], res[False][2]) < 1e-4
+
+
+def test_sliding_window_driver_on_gpu(tmp_path):
+    """pde_amd.drivers.sliding_window end to end on the HIP path (synthetic travelling wave, 3 windows,
+    short Adam phases with HIP-graph replay): runs, saves/reloads its window models, stitches."""
+    from pde_amd import drivers
+    x = np.linspace(-10, 10, 64)[:, None]
+    t = np.linspace(-2, 2, 21)[:, None]
+    exact = 0.5 / np.cosh(0.5 * (x.T - 0.25 * t)) ** 2
+    cls = type("SW", (scripts.kdv5_1soliton.sw.PhysicsInformedNN,), {"base_dir": str(tmp_path), "use_hip_graph": True})
+    models, full, err = drivers.sliding_window(cls, [2, 50, 50, 50, 50, 1], x, t, exact, N0=32, Nb=16, Nf=2000,
+                                               n_overlap=16, nIter=30, LBFGS_max_iter=0, log_name=None,
+                                               rng=np.random.default_rng(0))
+    assert len(models) == 3 and np.isfinite(err) and full.shape == (21 * 64, 1)
+    _, full2, err2 = drivers.sliding_window(cls, [2, 50, 50, 50, 50, 1], x, t, exact, train=False)
+    assert np.allclose(full2, full, atol=1e-6) and abs(err2 - err) < 1e-6
