@@ -23,17 +23,18 @@ def lhs(n, samples, rng=None):
     return out
 
 
-def load_mat(path, key=None):
+def load_mat(path, key=None, complex_valued=False):
     """``t, x, Exact_u`` of one of the reference's data files: ``t`` (T,1), ``x`` (X,1), real part of
     ``uu`` as (T,X) (``7kdv/sw-73.py:225-229``); Burgers' ``usol`` is stored (X,T) and transposed
-    (``Burgers/Burgers_equation(PINN).py:194-201``)."""
+    (``Burgers/Burgers_equation(PINN).py:194-201``).  ``complex_valued=True`` keeps ``uu`` complex
+    (NLS/GNSS: u = Re, v = Im, ``NLS/sw-GNSS-adamW.py:241-244``)."""
     import scipy.io
     data = scipy.io.loadmat(path)
     t = data['t'].flatten()[:, None]
     x = data['x'].flatten()[:, None]
     if key is None:
         key = 'uu' if 'uu' in data else 'usol'
-    exact = np.real(data[key])
+    exact = data[key] if complex_valued else np.real(data[key])
     if exact.shape == (x.shape[0], t.shape[0]) and x.shape[0] != t.shape[0]:
         exact = exact.T
     return t, x, exact
@@ -62,16 +63,28 @@ def sliding_window(model_cls, layers, x, t, exact_u, *, num_windows=3, window_fr
     model.  Each window's model predicts the whole grid; its values are kept inside its own time range
     (later windows overwrite the overlap), points no window covers are filled by the last model.
     Returns ``(models, full_u_pred, relative L2 error)``.  With ``train=False`` the per-window models
-    are loaded from ``<base_dir>/model/<model_name>`` instead."""
+    are loaded from ``<base_dir>/model/<model_name>`` instead.
+
+    Two-output nets (NLS/GNSS, ``NLS/sw-GNSS-adamW.py:262-404``): pass ``exact_u`` complex (or a
+    ``(u, v)`` pair); initial, overlap and stitched fields are then pairs, and the function returns
+    ``(models, (full_u, full_v, full_h), (err_u, err_v, err_h))`` with ``h = sqrt(u^2 + v^2)``."""
     rng = np.random.default_rng(1234) if rng is None else rng
     X_star = grid_points(x, t)
-    u_star = exact_u.flatten()[:, None]
+    if isinstance(exact_u, (tuple, list)):
+        fields = [np.asarray(exact_u[0]), np.asarray(exact_u[1])]
+    elif np.iscomplexobj(exact_u):
+        fields = [np.real(exact_u), np.imag(exact_u)]
+    else:
+        fields = [np.asarray(exact_u)]
+    two = len(fields) == 2
+    as_list = (lambda r: list(r)) if two else (lambda r: [r])
+    stars = [f.flatten()[:, None] for f in fields]
     lb, ub = X_star.min(0), X_star.max(0)
     window = (ub[1] - lb[1]) * window_frac
     step = window * step_frac
 
     models, prev_model = [], None
-    full = np.zeros_like(u_star)
+    full = [np.zeros_like(s_) for s_ in stars]
     done = np.zeros(len(X_star), dtype=bool)
     for win in range(num_windows):
         t_min = lb[1] + win * step
@@ -80,12 +93,13 @@ def sliding_window(model_cls, layers, x, t, exact_u, *, num_windows=3, window_fr
         name = model_name.format(win=win + 1)
         if train:
             idx = rng.choice(len(x), N0, replace=False)
+            x0 = x[idx]
+            prev_vals = []
+            X_prev = None
             if win == 0:
-                x0, u0 = x[idx], exact_u[0, :].reshape(-1, 1)[idx]
-                X_prev = u_prev = None
+                ic = [f[0, :].reshape(-1, 1)[idx] for f in fields]
             else:
-                u_init = prev_model.predict(np.hstack((x, np.ones_like(x) * t_min)))
-                x0, u0 = x[idx], u_init[idx]
+                ic = [r[idx] for r in as_list(prev_model.predict(np.hstack((x, np.ones_like(x) * t_min))))]
                 prev_t_min = lb[1] + (win - 1) * step
                 prev_t_max = min(prev_t_min + window, ub[1])
                 o_min, o_max = max(prev_t_min, t_min), min(prev_t_max, t_max)
@@ -93,15 +107,15 @@ def sliding_window(model_cls, layers, x, t, exact_u, *, num_windows=3, window_fr
                     X_prev = np.zeros((n_overlap, 2))
                     X_prev[:, 0] = lb[0] + (ub[0] - lb[0]) * rng.random(n_overlap)
                     X_prev[:, 1] = o_min + (o_max - o_min) * rng.random(n_overlap)
-                    u_prev = prev_model.predict(X_prev)
-                else:
-                    X_prev = u_prev = None
+                    prev_vals = as_list(prev_model.predict(X_prev))
             tb = t_min + (t_max - t_min) * lhs(1, Nb, rng)
             Xf = np.zeros((Nf, 2))
             Xf[:, 0] = win_lb[0] + (win_ub[0] - win_lb[0]) * lhs(1, Nf, rng).flatten()
             Xf[:, 1] = t_min + (t_max - t_min) * lhs(1, Nf, rng).flatten()
             model = model_cls(layers, win_lb, win_ub, prev_model)
-            model.set_training_data(x0, u0, tb, Xf, X_prev, u_prev)
+            if X_prev is None:
+                prev_vals = [None] * len(fields)
+            model.set_training_data(x0, *ic, tb, Xf, X_prev, *prev_vals)
             model.train(nIter, log_name.format(win=win + 1) if log_name else None, LBFGS_max_iter=LBFGS_max_iter)
             model.save_model(name)
         else:
@@ -109,13 +123,20 @@ def sliding_window(model_cls, layers, x, t, exact_u, *, num_windows=3, window_fr
             model.load_model(name)
         prev_model = model
         models.append(model)
-        u_pred = model.predict(X_star)
+        preds = as_list(model.predict(X_star))
         mask = (X_star[:, 1] >= t_min) & (X_star[:, 1] <= t_max)
-        full[mask] = u_pred[mask]
+        for f_, p_ in zip(full, preds):
+            f_[mask] = p_[mask]
         done[mask] = True
     if not np.all(done):
-        full[~done] = prev_model.predict(X_star[~done])
-    return models, full, relative_l2(full, u_star)
+        for f_, p_ in zip(full, as_list(prev_model.predict(X_star[~done]))):
+            f_[~done] = p_
+    if not two:
+        return models, full[0], relative_l2(full[0], stars[0])
+    full_h = np.sqrt(full[0] ** 2 + full[1] ** 2)
+    h_star = np.sqrt(stars[0] ** 2 + stars[1] ** 2)
+    return models, (full[0], full[1], full_h), (relative_l2(full[0], stars[0]), relative_l2(full[1], stars[1]),
+                                                 relative_l2(full_h, h_star))
 
 
 def backward_compatible(pi_cls, bc_cls, layers, x, t, exact_u, *, step=50, N0=100, Nf=20000, nIter=5000,

@@ -85,3 +85,33 @@ def test_backward_compatible_segments(tmp_path):
     assert models[1].x1.shape[0] == 11 * 24                                      # history grid = rows 0..10
     assert np.isclose(float(models[1].t0[0, 0]), t[10, 0])                       # IC pinned at the segment's left edge
     assert u1.shape == (21 * 24, 1)
+
+
+def test_sliding_window_two_output_gnss(tmp_path):
+    """NLS/GNSS nets predict (u, v): complex data in, stitched (u, v, h) and three errors out
+    (NLS/sw-GNSS-adamW.py:262-404)."""
+    x, t, exact = _toy()
+    uu = exact * np.exp(1j * (0.7 * x.T + 0.3 * t))                               # (T, X) complex
+    cls = install(scripts.gnss.sw.PhysicsInformedNN)
+    cls.base_dir = str(tmp_path)
+    models, (fu, fv, fh), errs = drivers.sliding_window(cls, [2, 6, 6, 2], x, t, uu, N0=10, Nb=6, Nf=40,
+                                                        n_overlap=8, nIter=2, LBFGS_max_iter=0,
+                                                        rng=np.random.default_rng(0))
+    assert len(models) == 3 and fu.shape == fv.shape == fh.shape == (21 * 24, 1)
+    assert len(errs) == 3 and all(np.isfinite(e) for e in errs)
+    assert np.allclose(fh, np.sqrt(fu ** 2 + fv ** 2))
+    X = drivers.grid_points(x, t)
+    last = X[:, 1] >= 0.0 - 1e-12                                                # the last window owns [0, .5]
+    u3, v3 = models[2].predict(X[last])
+    assert np.allclose(fu[last], u3, atol=1e-6) and np.allclose(fv[last], v3, atol=1e-6)
+    # window 1: IC from the data's first row; window 2: overlap labels for both outputs
+    assert models[0].X_prev is None
+    assert models[1].X_prev.shape[0] == 8 and models[1].u_prev.shape == (8, 1) and models[1].v_prev.shape == (8, 1)
+    # a (u, v) pair is accepted like complex data
+    _, _, errs2 = drivers.sliding_window(cls, [2, 6, 6, 2], x, t, (uu.real, uu.imag), train=False)
+    assert np.allclose(errs2, errs, atol=1e-6)
+    # complex .mat loading keeps the imaginary part
+    import scipy.io
+    p = os.path.join(tmp_path, "nls.mat")
+    scipy.io.savemat(p, {"t": t, "x": x, "uu": uu})
+    assert np.allclose(drivers.load_mat(p, complex_valued=True)[2], uu)
