@@ -117,6 +117,27 @@ int pinn_loss_grad(pinn_handle *h, const float *theta, const float *x, const flo
                    int64_t stride, int64_t n, float scale, float *loss_sums_accum,
                    float *grad_theta_accum, void *stream);
 
+/* ---- L-BFGS on the device --------------------------------------------------
+ * The reference ends every run with torch.optim.LBFGS.step(closure), strong-Wolfe
+ * (7kdv/PI-7kdv3soliton.py:138-161; third-party torch/optim/lbfgs.py).  These two entry points
+ * replace that optimizer's per-iteration tensor work with one launch each; the line search's
+ * scalar logic stays on the host (pde_amd/lbfgs.py).  No handle: plain device vectors of n floats.
+ *
+ * workspace: pinn_lbfgs_workspace_floats(n, history) floats, caller-allocated, kept between calls
+ *            (history ring S/Y, 1/y.s, previous gradient, H_diag); contents are (re)initialised by
+ *            a call with first != 0.  history <= 512, n <= 2^24.
+ * pinn_lbfgs_direction: with first != 0: d = -g.  Otherwise: y = g - g_prev, s = t*d (d and t of
+ *            the previous call/step), pair stored if y.s > 1e-10 (oldest dropped when full),
+ *            H = y.s/y.y, d = two-loop recursion applied to -g.  Always: g_prev = g and
+ *            stats8 = [g.d, sum|g|, max|d|, max|g|, pairs held, H_diag, 0, 0].
+ * pinn_lbfgs_eval_stats: out4 = [*loss (0 when NULL), g.d, max|g|, sum|g|] after one closure
+ *            evaluation of the line search. */
+int64_t pinn_lbfgs_workspace_floats(int64_t n, int32_t history);
+int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const float *g, float *d, float t,
+                         int32_t first, float *stats8, void *stream);
+int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float *loss, float *out4,
+                          void *stream);
+
 const char *pinn_error_string(int code);
 
 #define PINN_OK 0

@@ -38,6 +38,7 @@ SYMBOLS = [
     "pinn_create", "pinn_destroy", "pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout",
     "pinn_kernel_kind", "pinn_forward", "pinn_forward_vjp", "pinn_residual_fwd", "pinn_residual_vjp",
     "pinn_loss_grad", "pinn_error_string",
+    "pinn_lbfgs_workspace_floats", "pinn_lbfgs_direction", "pinn_lbfgs_eval_stats",
 ]
 
 
@@ -61,6 +62,10 @@ def load_library():
     lib.pinn_residual_fwd.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_residual_vjp.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_loss_grad.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp, vp, vp]
+    lib.pinn_lbfgs_workspace_floats.argtypes = [i64, ctypes.c_int32]
+    lib.pinn_lbfgs_workspace_floats.restype = i64
+    lib.pinn_lbfgs_direction.argtypes = [vp, i64, ctypes.c_int32, vp, vp, f32, ctypes.c_int32, vp, vp]
+    lib.pinn_lbfgs_eval_stats.argtypes = [vp, vp, i64, vp, vp, vp]
     lib.pinn_error_string.argtypes = [ctypes.c_int]
     lib.pinn_error_string.restype = ctypes.c_char_p
     _lib = lib
@@ -183,3 +188,44 @@ class NativeEngine:
             _check(self.lib.pinn_loss_grad(self._h, theta.data_ptr(), px, pt, stride, n, float(scale),
                                            loss_sums_accum.data_ptr(), grad_accum.data_ptr(), self._stream()),
                    "pinn_loss_grad")
+
+
+class NativeLBFGSKernels:
+    """Device side of pde_amd.lbfgs.LBFGS: the history ring and the two launches of
+    include/pinnjet.h's pinn_lbfgs_* entry points, on torch's current stream."""
+
+    def __init__(self, n, history, device):
+        if not torch.cuda.is_available():
+            raise NativeError("pde_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.device(device)
+        self.n, self.history = int(n), int(history)
+        floats = self.lib.pinn_lbfgs_workspace_floats(self.n, self.history)
+        if floats <= 0:
+            raise NativeError("pinn_lbfgs_workspace_floats(%d, %d) failed (%d)" % (n, history, floats))
+        self.ws = torch.zeros(floats, dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.out = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, v):
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == self.n and v.device == self.device
+
+    def direction(self, g, d, t, first):
+        self._chk(g); self._chk(d)
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_lbfgs_direction(self.ws.data_ptr(), self.n, self.history, g.data_ptr(), d.data_ptr(),
+                                                 float(t), 1 if first else 0, self.stats.data_ptr(), self._stream()),
+                   "pinn_lbfgs_direction")
+        return self.stats
+
+    def eval_stats(self, g, d, loss):
+        self._chk(g); self._chk(d)
+        loss = loss.detach().reshape(-1).float()
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_lbfgs_eval_stats(g.data_ptr(), d.data_ptr(), self.n, loss.data_ptr(),
+                                                  self.out.data_ptr(), self._stream()), "pinn_lbfgs_eval_stats")
+        return self.out

@@ -1,0 +1,263 @@
+"""L-BFGS with strong-Wolfe line search whose vector work stays on the GPU.
+
+Every reference script ends `train()` with ONE `torch.optim.LBFGS(...).step(closure)` of up to
+50 000 closure evaluations (7kdv/PI-7kdv3soliton.py:138-161) — at the scripts' own sizes that is
+where most of the wall time goes.  torch's optimizer issues several tiny tensor ops per history
+pair and blocks on the device for every scalar it compares.  This class is the same algorithm
+(same constructor arguments, same `step(closure)` protocol and stopping rules, same history
+update / two-loop recursion / bracketing / zoom / cubic interpolation, so a run follows the
+trajectory of `torch.optim.LBFGS` up to float32 summation order) arranged differently:
+
+  * parameters and gradients are ONE flat buffer each (`p.grad` are views, so the closure's
+    `loss.backward()` accumulates straight into it — no gather/scatter ops);
+  * the direction update is one kernel launch (`pinn_lbfgs_direction`, csrc/lbfgs.hip);
+  * each closure evaluation is followed by one launch that packs [loss, g.d, max|g|] and ONE
+    device->host read; all line-search arithmetic runs on Python floats.
+
+There is no CPU fallback in the product: without the HIP library the constructor raises.
+(`kernels=` is the seam tests/ uses to drive the host logic on the CPU.)
+"""
+import math
+
+import torch
+
+
+def _cubic_min(x1, f1, g1, x2, f2, g2, bounds=None):
+    """Minimiser of the cubic through (x1,f1,g1), (x2,f2,g2), clipped to `bounds`
+    (default: the interval between the two points); midpoint when the cubic has no minimum."""
+    if bounds is not None:
+        lo, hi = bounds
+    else:
+        lo, hi = (x1, x2) if x1 <= x2 else (x2, x1)
+    if x1 == x2:
+        return min(max(x1, lo), hi)
+    d1 = g1 + g2 - 3.0 * (f1 - f2) / (x1 - x2)
+    disc = d1 * d1 - g1 * g2
+    if disc >= 0.0:
+        d2 = math.sqrt(disc)
+        den = (g2 - g1 if x1 <= x2 else g1 - g2) + 2.0 * d2
+        if den != 0.0:
+            if x1 <= x2:
+                pos = x2 - (x2 - x1) * ((g2 + d2 - d1) / den)
+            else:
+                pos = x1 - (x1 - x2) * ((g1 + d2 - d1) / den)
+            if pos == pos:
+                return min(max(pos, lo), hi)
+    return (lo + hi) / 2.0
+
+
+class _Point:
+    """One evaluated step length of the line search."""
+    __slots__ = ("t", "f", "g", "gtd", "gmax")
+
+    def __init__(self, t, f, g, gtd, gmax):
+        self.t, self.f, self.g, self.gtd, self.gmax = t, f, g, gtd, gmax
+
+
+class LBFGS(torch.optim.Optimizer):
+    """Drop-in for `torch.optim.LBFGS` (one parameter group, dense float32 parameters on one
+    device).  `flat_params`: the contiguous buffer the parameters are views of, in order
+    (NetU.flat_theta()); when omitted the parameters are re-pointed into a new flat buffer."""
+
+    def __init__(self, params, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9,
+                 history_size=100, line_search_fn=None, flat_params=None, kernels=None):
+        if max_eval is None:
+            max_eval = max_iter * 5 // 4
+        if line_search_fn not in (None, "strong_wolfe"):
+            raise RuntimeError("only 'strong_wolfe' is supported")
+        defaults = dict(lr=lr, max_iter=max_iter, max_eval=max_eval, tolerance_grad=tolerance_grad,
+                        tolerance_change=tolerance_change, history_size=history_size, line_search_fn=line_search_fn)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("LBFGS doesn't support per-parameter options (parameter groups)")
+        self._params = self.param_groups[0]["params"]
+        n = sum(p.numel() for p in self._params)
+        dev = self._params[0].device
+        if flat_params is None:
+            flat_params = torch.cat([p.detach().reshape(-1).float() for p in self._params]).contiguous()
+            off = 0
+            for p in self._params:
+                p.data = flat_params[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+        else:
+            off = 0
+            for p in self._params:
+                if p.data_ptr() != flat_params.data_ptr() + 4 * off or p.dtype != torch.float32:
+                    raise ValueError("flat_params is not the buffer the parameters are views of")
+                off += p.numel()
+            if off != flat_params.numel():
+                raise ValueError("flat_params has %d elements, the parameters %d" % (flat_params.numel(), off))
+        self._x = flat_params
+        self._g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._d = torch.zeros(n, dtype=torch.float32, device=dev)
+        if kernels is None:
+            from ._native import NativeLBFGSKernels
+            kernels = NativeLBFGSKernels(n, history_size, dev)
+        self._k = kernels
+        self._host = torch.empty(8, dtype=torch.float32, pin_memory=True) if dev.type == "cuda" else None
+        self._attach_grads()
+        st = self.state[self._params[0]]
+        st.setdefault("func_evals", 0)
+        st.setdefault("n_iter", 0)
+        self.host_syncs = 0
+
+    # ---- flat gradient -------------------------------------------------------------------
+    def _attach_grads(self):
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            want = self._g.data_ptr() + 4 * off
+            if p.grad is None or p.grad.data_ptr() != want:
+                p.grad = self._g[off:off + n].view(p.shape)
+            off += n
+
+    def zero_grad(self, set_to_none=True):
+        """Zeroes the flat gradient; `.grad` stay views into it (never set to None)."""
+        self._g.zero_()
+        self._attach_grads()
+
+    def _gather(self):
+        """Flat gradient after a closure; copies only what a foreign zero_grad()/backward re-pointed."""
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            seg = self._g[off:off + n]
+            if p.grad is None:
+                seg.zero_()
+            elif p.grad.data_ptr() != seg.data_ptr():
+                seg.copy_(p.grad.reshape(-1))
+            off += n
+        return self._g
+
+    def _read(self, dev_vec):
+        """device floats -> Python floats: the one blocking read per evaluation."""
+        self.host_syncs += 1
+        if self._host is None:
+            return [float(v) for v in dev_vec.tolist()]
+        k = dev_vec.numel()
+        self._host[:k].copy_(dev_vec, non_blocking=True)
+        torch.cuda.current_stream(dev_vec.device).synchronize()
+        return self._host[:k].tolist()
+
+    # ---- one closure evaluation at x0 + t d ------------------------------------------------
+    def _evaluate(self, closure, x0, t):
+        torch.add(x0, self._d, alpha=t, out=self._x)
+        loss = closure()
+        g = self._gather()
+        f, gtd, gmax, _ = self._read(self._k.eval_stats(g, self._d, loss))
+        return _Point(t, f, g.clone(), gtd, gmax)
+
+    def _strong_wolfe(self, closure, x0, t, f0, g0, gtd0, gmax0, d_norm, c1=1e-4, c2=0.9, tolerance_change=1e-9,
+                      max_ls=25):
+        """Bracketing + zoom phases of the strong-Wolfe search (Nocedal & Wright alg. 3.5/3.6 as
+        arranged in torch.optim.lbfgs._strong_wolfe).  Returns (accepted point, evaluations)."""
+        start = _Point(0.0, f0, g0, gtd0, gmax0)
+        new = self._evaluate(closure, x0, t)
+        evals, prev, it = 1, start, 0
+        done, bracket = False, None
+        while it < max_ls:
+            if new.f > f0 + c1 * new.t * gtd0 or (it > 1 and new.f >= prev.f):
+                bracket = [prev, new]
+                break
+            if abs(new.gtd) <= -c2 * gtd0:
+                bracket, done = [new], True
+                break
+            if new.gtd >= 0:
+                bracket = [prev, new]
+                break
+            lo = new.t + 0.01 * (new.t - prev.t)
+            hi = new.t * 10
+            t_next = _cubic_min(prev.t, prev.f, prev.gtd, new.t, new.f, new.gtd, bounds=(lo, hi))
+            prev = new
+            new = self._evaluate(closure, x0, t_next)
+            evals += 1
+            it += 1
+        if it == max_ls:
+            bracket = [start, new]
+        # zoom: shrink the bracket until a point satisfies both conditions or it collapses
+        insuf = False
+        low, high = (0, 1) if bracket[0].f <= bracket[-1].f else (1, 0)
+        while not done and it < max_ls:
+            if abs(bracket[1].t - bracket[0].t) * d_norm < tolerance_change:
+                break
+            t_new = _cubic_min(bracket[0].t, bracket[0].f, bracket[0].gtd, bracket[1].t, bracket[1].f, bracket[1].gtd)
+            b_hi, b_lo = max(bracket[0].t, bracket[1].t), min(bracket[0].t, bracket[1].t)
+            eps = 0.1 * (b_hi - b_lo)
+            if min(b_hi - t_new, t_new - b_lo) < eps:
+                if insuf or t_new >= b_hi or t_new <= b_lo:
+                    t_new = b_hi - eps if abs(t_new - b_hi) < abs(t_new - b_lo) else b_lo + eps
+                    insuf = False
+                else:
+                    insuf = True
+            else:
+                insuf = False
+            new = self._evaluate(closure, x0, t_new)
+            evals += 1
+            it += 1
+            if new.f > f0 + c1 * new.t * gtd0 or new.f >= bracket[low].f:
+                bracket[high] = new
+                low, high = (0, 1) if bracket[0].f <= bracket[1].f else (1, 0)
+            else:
+                if abs(new.gtd) <= -c2 * gtd0:
+                    done = True
+                elif new.gtd * (bracket[high].t - bracket[low].t) >= 0:
+                    bracket[high] = bracket[low]
+                bracket[low] = new
+        return (bracket[low] if len(bracket) > 1 else bracket[0]), evals
+
+    @torch.no_grad()
+    def step(self, closure):
+        """Up to `max_iter` L-BFGS iterations / `max_eval` closure evaluations; returns the first
+        loss, like torch.optim.LBFGS.step."""
+        grp = self.param_groups[0]
+        lr, max_iter, max_eval = grp["lr"], grp["max_iter"], grp["max_eval"]
+        tol_g, tol_x = grp["tolerance_grad"], grp["tolerance_change"]
+        wolfe = grp["line_search_fn"] == "strong_wolfe"
+        closure = torch.enable_grad()(closure)
+        st = self.state[self._params[0]]
+
+        orig_loss = closure()
+        g = self._gather()
+        f, _, gmax, _ = self._read(self._k.eval_stats(g, self._d, orig_loss))
+        evals = 1
+        st["func_evals"] += 1
+        if gmax <= tol_g:
+            return orig_loss
+        g = g.clone()
+        t = st.get("t", lr)
+        n_iter = 0
+        while n_iter < max_iter:
+            n_iter += 1
+            st["n_iter"] += 1
+            first = st["n_iter"] == 1
+            gtd, gsum, dmax, _gm, _cnt, _hd, _, _ = self._read(self._k.direction(g, self._d, t, first))
+            prev_f = f
+            t = min(1.0, 1.0 / gsum) * lr if first else lr
+            if gtd > -tol_x:
+                break
+            if wolfe:
+                x0 = self._x.clone()
+                pt, ls_evals = self._strong_wolfe(closure, x0, t, f, g, gtd, gmax, dmax)
+                t, f, g, gmax = pt.t, pt.f, pt.g, pt.gmax
+                torch.add(x0, self._d, alpha=t, out=self._x)
+            else:
+                self._x.add_(self._d, alpha=t)
+                ls_evals = 0
+                if n_iter != max_iter:
+                    loss = closure()
+                    gv = self._gather()
+                    f, _, gmax, _ = self._read(self._k.eval_stats(gv, self._d, loss))
+                    g = gv.clone()
+                    ls_evals = 1
+            evals += ls_evals
+            st["func_evals"] += ls_evals
+            if n_iter == max_iter or evals >= max_eval:
+                break
+            if gmax <= tol_g:
+                break
+            if dmax * abs(t) <= tol_x:
+                break
+            if abs(f - prev_f) < tol_x:
+                break
+        st["t"] = t
+        return orig_loss

@@ -61,6 +61,8 @@ class PhysicsInformedNN:
     default_device = None            # None -> current CUDA device
     kernel = KERNEL_AUTO
     use_hip_graph = False            # train(): replay the Adam phase from a captured HIP graph (single process)
+    lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (one launch per direction); "torch": torch.optim.LBFGS
+    lbfgs_kernels_factory = None     # test hook: callable(n, history) -> stand-in for the L-BFGS launches
     engine_factory = None            # test hook: callable(equation|None, layers, lb, ub, device) -> engine
 
     def __init__(self, layers, lb, ub, prev_model=None, process_group=None):
@@ -302,11 +304,19 @@ class PhysicsInformedNN:
             self.optimizer_Adam = torch.optim.AdamW(params, weight_decay=v.weight_decay)
         else:
             self.optimizer_Adam = torch.optim.Adam(params)
-        self.optimizer_LBFGS = torch.optim.LBFGS(
-            params, lr=v.lbfgs.get("lr", 1.0), max_iter=LBFGS_max_iter,
-            max_eval=v.lbfgs.get("max_eval", 5000), history_size=v.lbfgs.get("history_size", 50),
-            tolerance_grad=v.lbfgs.get("tolerance_grad", 1e-5),
-            tolerance_change=1.0 * np.finfo(float).eps, line_search_fn="strong_wolfe")
+        lbfgs_kw = dict(lr=v.lbfgs.get("lr", 1.0), max_iter=LBFGS_max_iter,
+                        max_eval=v.lbfgs.get("max_eval", 5000), history_size=v.lbfgs.get("history_size", 50),
+                        tolerance_grad=v.lbfgs.get("tolerance_grad", 1e-5),
+                        tolerance_change=1.0 * np.finfo(float).eps, line_search_fn="strong_wolfe")
+        kfac = type(self).lbfgs_kernels_factory
+        if self.lbfgs_impl == "device" and (torch.device(self.device).type == "cuda" or kfac is not None):
+            from .lbfgs import LBFGS
+            theta = self.dnn.flat_theta()
+            self.optimizer_LBFGS = LBFGS(params, flat_params=theta,
+                                         kernels=kfac(theta.numel(), lbfgs_kw["history_size"]) if kfac else None,
+                                         **lbfgs_kw)
+        else:
+            self.optimizer_LBFGS = torch.optim.LBFGS(params, **lbfgs_kw)
         self.logfilename = logfilename if self._is_rank0() else None
         if self.logfilename is not None:
             self.writer = FileWriter(logfilename, self.base_dir)
