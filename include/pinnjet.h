@@ -124,12 +124,15 @@ int pinn_loss_grad(pinn_handle *h, const float *theta, const float *x, const flo
  * scalar logic stays on the host (pde_amd/lbfgs.py).  No handle: plain device vectors of n floats.
  *
  * workspace: pinn_lbfgs_workspace_floats(n, history) floats, caller-allocated, kept between calls
- *            (history ring S/Y, 1/y.s, previous gradient, H_diag); contents are (re)initialised by
- *            a call with first != 0.  history <= 512, n <= 2^24.
+ *            (history rows S/Y, their Gram matrices in float64, previous gradient, H_diag); 8-byte
+ *            aligned; contents are (re)initialised by a call with first != 0.  history <= 256,
+ *            n <= 2^24.
  * pinn_lbfgs_direction: with first != 0: d = -g.  Otherwise: y = g - g_prev, s = t*d (d and t of
  *            the previous call/step), pair stored if y.s > 1e-10 (oldest dropped when full),
  *            H = y.s/y.y, d = two-loop recursion applied to -g.  Always: g_prev = g and
- *            stats8 = [g.d, sum|g|, max|d|, max|g|, pairs held, H_diag, 0, 0].
+ *            stats8 = [g.d, sum|g|, max|d|, max|g|, pairs held, H_diag, pair accepted (0/1), 0].
+ *            Four launches (row dot products over the whole chip, the scalar recursion, the
+ *            combination, the statistics); deterministic (fixed-order reductions, no atomics).
  * pinn_lbfgs_eval_stats: out4 = [*loss (0 when NULL), g.d, max|g|, sum|g|] after one closure
  *            evaluation of the line search. */
 int64_t pinn_lbfgs_workspace_floats(int64_t n, int32_t history);

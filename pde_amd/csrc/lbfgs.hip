@@ -5,15 +5,24 @@
 // implementation runs the two-loop recursion as ~6 tiny tensor ops per history pair
 // (300-900 launches per iteration at history 50-150) plus a host sync for every
 // scalar it branches on; at the scripts' native sizes (N_f = 20 000) that costs several
-// times more than the closure itself.  Here one launch does, in the same order of
-// operations as the textbook recursion:
-//     y = g - g_prev, s = t*d, curvature test y.s > 1e-10, history ring update,
-//     H = y.s / y.y, q = -g, first loop (newest -> oldest), r = H q,
-//     second loop (oldest -> newest), d = r, g_prev = g,
-// and leaves the scalars the host's line search needs (g.d, sum|g|, max|d|, max|g|)
-// in a small device buffer.  P is 7 851 .. 30 802 floats, so one 1024-thread
-// workgroup streams the history out of L2; every reduction is a fixed-order tree,
-// which keeps the result deterministic and identical on every rank.
+// times more than the closure itself.
+//
+// The two-loop recursion is sequential only in its SCALARS: every inner product it takes
+// (s_k.q, y_k.r with q, r partially updated) is a linear combination of inner products
+// among {g, s_j, y_j}.  So one direction update is arranged as four chip-wide launches
+//   k_dots     every live history row (and the candidate pair y = g - g_prev, s = t d,
+//              formed on the fly) against g and the candidate: 5 dot products per row,
+//              float products accumulated in float64, per-chunk partials (no atomics);
+//   k_scalars  one workgroup: curvature test y.s > 1e-10, history bookkeeping, the new
+//              row/column of the Gram matrices S.Y^T and Y.Y^T, H = y.s/y.y, and the
+//              two-loop recursion itself on (history x history) float64 scalars;
+//   k_combine  d = -H g + sum_k aY_k y_k + sum_k aS_k s_k per element, stores the accepted
+//              pair, g_prev = g, per-block partials of g.d, sum|g|, max|d|, max|g|;
+//   k_stats    one workgroup folds those partials into the 8 floats the host reads.
+// It is the same recursion as torch's (same pairs, same curvature test, same H), evaluated
+// in exact-product float64 instead of float32, so it tracks the exact-arithmetic direction
+// more closely than the float32 loop does.  All reductions have a fixed order: the result
+// is deterministic and identical on every rank holding the same gradient.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -21,207 +30,404 @@
 
 namespace {
 
-constexpr int LB_THREADS = 1024;
-constexpr int LB_WAVES = LB_THREADS / 64;
-constexpr int LB_HDR = 16;          // floats: [0] pairs held, [1] ring head, [2] H_diag
-constexpr int LB_MAX_HISTORY = 512;
+constexpr int LB_MAX_HISTORY = 256;
+constexpr int LB_CHUNK = 2048;      // elements per workgroup of k_dots / k_combine
+constexpr int LB_BLOCK = 256;
+constexpr int LB_EPT = LB_CHUNK / LB_BLOCK;
+constexpr int LB_NDOT = 5;
 
-__device__ inline float wave_sum(float v) {
+// workspace header (ints), then float64 scalars, then float vectors; offsets in BYTES
+struct LbLayout {
+    int64_t hdr;        // int[8]: count, free slot, accept flag
+    int64_t ord;        // int[hist+1]: physical slot of logical pair k (oldest first)
+    int64_t H;          // double[2]: H_diag
+    int64_t ro;         // double[hist+1] by physical slot
+    int64_t b, c;       // double[hist+1]: s_j.g, y_j.g by physical slot
+    int64_t SY, YY;     // double[(hist+1)^2] by physical slots: s_a.y_b, y_a.y_b
+    int64_t coefY, coefS;  // double[hist+1] by logical index, coefG = coefY[hist+1 ...]
+    int64_t part;       // double[(hist+1) * nchunk * LB_NDOT]
+    int64_t spart;      // double[ncomb * 4]
+    int64_t prev_g;     // float[np]
+    int64_t S, Y;       // float[(hist+1) * np]
+    int64_t total;
+    int np, nchunk, ncomb, slots;
+};
+inline __host__ __device__ int64_t al256(int64_t v) { return (v + 255) & ~int64_t(255); }
+inline __host__ __device__ LbLayout lb_layout(int64_t n, int hist) {
+    LbLayout L;
+    L.slots = hist + 1;
+    L.np = (int)((n + 63) & ~int64_t(63));
+    L.nchunk = (int)((n + LB_CHUNK - 1) / LB_CHUNK);
+    L.ncomb = (int)((n + LB_BLOCK - 1) / LB_BLOCK);
+    int64_t o = 0;
+    L.hdr = o; o = al256(o + 8 * 4);
+    L.ord = o; o = al256(o + int64_t(L.slots) * 4);
+    L.H = o; o = al256(o + 16);
+    L.ro = o; o = al256(o + int64_t(L.slots) * 8);
+    L.b = o; o = al256(o + int64_t(L.slots) * 8);
+    L.c = o; o = al256(o + int64_t(L.slots) * 8);
+    L.SY = o; o = al256(o + int64_t(L.slots) * L.slots * 8);
+    L.YY = o; o = al256(o + int64_t(L.slots) * L.slots * 8);
+    L.coefY = o; o = al256(o + int64_t(L.slots + 1) * 8);
+    L.coefS = o; o = al256(o + int64_t(L.slots + 1) * 8);
+    L.part = o; o = al256(o + int64_t(L.slots) * L.nchunk * LB_NDOT * 8);
+    L.spart = o; o = al256(o + int64_t(L.ncomb) * 4 * 8);
+    L.prev_g = o; o = al256(o + int64_t(L.np) * 4);
+    L.S = o; o = al256(o + int64_t(L.slots) * L.np * 4);
+    L.Y = o; o = al256(o + int64_t(L.slots) * L.np * 4);
+    L.total = o;
+    return L;
+}
+
+template <typename T> __device__ inline T *at(char *ws, int64_t off) { return reinterpret_cast<T *>(ws + off); }
+
+__device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-__device__ inline float wave_max(float v) {
+__device__ inline double wave_max(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
 
-// Block-wide reduction of NV sums and NM maxima; every thread leaves with the same values
-// (all of them add the per-wave partials in the same order).
+// block-wide reduction (LB_BLOCK threads = 4 waves) of NV sums then NM maxima; valid on thread 0
 template <int NV, int NM>
-__device__ inline void block_reduce(float (&s)[NV], float (&m)[NM > 0 ? NM : 1], float *red) {
+__device__ inline void block_reduce(double (&v)[NV + NM], double *red) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) s[k] = wave_sum(s[k]);
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
 #pragma unroll
-    for (int k = 0; k < NM; ++k) m[k] = wave_max(m[k]);
-    __syncthreads();    // the previous reduction's readers are done with `red`
+    for (int k = NV; k < NV + NM; ++k) v[k] = wave_max(v[k]);
+    __syncthreads();
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) red[w * (NV + NM) + k] = s[k];
-#pragma unroll
-        for (int k = 0; k < NM; ++k) red[w * (NV + NM) + NV + k] = m[k];
+        for (int k = 0; k < NV + NM; ++k) red[w * (NV + NM) + k] = v[k];
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        float a = 0.f;
-        for (int i = 0; i < LB_WAVES; ++i) a += red[i * (NV + NM) + k];
-        s[k] = a;
-    }
-#pragma unroll
-    for (int k = 0; k < NM; ++k) {
-        float a = red[NV + k];
-        for (int i = 1; i < LB_WAVES; ++i) a = fmaxf(a, red[i * (NV + NM) + NV + k]);
-        m[k] = a;
+        for (int k = 0; k < NV + NM; ++k) {
+            double a = red[k];
+            for (int i = 1; i < LB_BLOCK / 64; ++i)
+                a = k < NV ? a + red[i * (NV + NM) + k] : fmax(a, red[i * (NV + NM) + k]);
+            v[k] = a;
+        }
     }
 }
 
-struct LbLayout {
-    int64_t ro, prev_g, q, S, Y, total;
-};
-inline __host__ __device__ LbLayout lb_layout(int64_t n, int hist) {
-    LbLayout L;
-    const int64_t np = (n + 3) & ~int64_t(3);
-    L.ro = LB_HDR;
-    L.prev_g = L.ro + ((hist + 3) & ~3);
-    L.q = L.prev_g + np;
-    L.S = L.q + np;
-    L.Y = L.S + int64_t(hist) * np;
-    L.total = L.Y + int64_t(hist) * np;
-    return L;
-}
-
-__global__ __launch_bounds__(LB_THREADS) void k_lbfgs_direction(float *__restrict__ ws, int n, int hist,
-                                                                const float *__restrict__ g, float *__restrict__ d,
-                                                                float t, int first, float *__restrict__ stats) {
-    __shared__ float red[LB_WAVES * 4];
-    __shared__ float al_s[LB_MAX_HISTORY];
+// ---- k_dots: grid (nchunk, slots).  Row = a live pair read from memory, or the candidate formed on the fly.
+__global__ __launch_bounds__(LB_BLOCK) void k_dots(char *__restrict__ ws, int n, int hist, const float *__restrict__ g,
+                                                   const float *__restrict__ d, float t) {
+    __shared__ double red[(LB_BLOCK / 64) * LB_NDOT];
     const LbLayout L = lb_layout(n, hist);
-    const int np = (n + 3) & ~3;
-    float *ro = ws + L.ro, *prev_g = ws + L.prev_g, *q = ws + L.q, *S = ws + L.S, *Y = ws + L.Y;
-    const int tid = threadIdx.x;
-    float dummy[1] = {0.f};
+    const int *hdr = at<int>(ws, L.hdr);
+    const int *ord = at<int>(ws, L.ord);
+    const int count = hdr[0], cand = hdr[1];
+    const int slot = blockIdx.y, chunk = blockIdx.x;
+    bool live = slot == cand;
+    for (int k = 0; k < count && !live; ++k) live = ord[k] == slot;
+    if (!live) return;                                   // uniform over the workgroup
+    const float *prev_g = at<float>(ws, L.prev_g);
+    const float *Sj = at<float>(ws, L.S) + int64_t(slot) * L.np;
+    const float *Yj = at<float>(ws, L.Y) + int64_t(slot) * L.np;
+    double a[LB_NDOT] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < LB_EPT; ++e) {
+        const int i = chunk * LB_CHUNK + e * LB_BLOCK + threadIdx.x;
+        if (i < n) {
+            const float gi = g[i];
+            const float yc = gi - prev_g[i], sc = d[i] * t;
+            const float sj = slot == cand ? sc : Sj[i];
+            const float yj = slot == cand ? yc : Yj[i];
+            a[0] = fma((double)sj, (double)gi, a[0]);    // s_j.g
+            a[1] = fma((double)yj, (double)gi, a[1]);    // y_j.g
+            a[2] = fma((double)sj, (double)yc, a[2]);    // s_j.y_c
+            a[3] = fma((double)sc, (double)yj, a[3]);    // s_c.y_j
+            a[4] = fma((double)yj, (double)yc, a[4]);    // y_j.y_c
+        }
+    }
+    block_reduce<LB_NDOT, 0>(a, red);
+    if (threadIdx.x == 0) {
+        double *p = at<double>(ws, L.part) + (int64_t(slot) * L.nchunk + chunk) * LB_NDOT;
+#pragma unroll
+        for (int k = 0; k < LB_NDOT; ++k) p[k] = a[k];
+    }
+}
 
-    int count = first ? 0 : (int)ws[0];
-    int head = first ? 0 : (int)ws[1];
-    float Hd = first ? 1.f : ws[2];
+// ---- k_scalars: one workgroup of 64 threads
+// `ldsn` > 0: the live part of S.Y^T is staged (in logical order) into ldsn x ldsn doubles of dynamic LDS, so
+// that a step of the sequential loops waits on LDS instead of on L2.
+__global__ __launch_bounds__(64) void k_scalars(char *__restrict__ ws, int n, int hist, int first, int ldsn) {
+    extern __shared__ double SYl[];
+    __shared__ double al[LB_MAX_HISTORY + 1], cc[LB_MAX_HISTORY + 1], pd[(LB_MAX_HISTORY + 1) * LB_NDOT];
+    __shared__ double Ak[LB_MAX_HISTORY + 1], rok[LB_MAX_HISTORY + 1], bk[LB_MAX_HISTORY + 1];
+    __shared__ int sord[LB_MAX_HISTORY + 1];
+    const LbLayout L = lb_layout(n, hist);
+    int *hdr = at<int>(ws, L.hdr);
+    int *ord = at<int>(ws, L.ord);
+    double *Hp = at<double>(ws, L.H), *ro = at<double>(ws, L.ro), *b = at<double>(ws, L.b), *c = at<double>(ws, L.c);
+    double *SY = at<double>(ws, L.SY), *YY = at<double>(ws, L.YY);
+    double *coefY = at<double>(ws, L.coefY), *coefS = at<double>(ws, L.coefS);
+    const double *part = at<double>(ws, L.part);
+    const int lane = threadIdx.x, slots = L.slots;
+
+    int count = first ? 0 : hdr[0];
+    int cand = first ? 0 : hdr[1];
+    double H = first ? 1.0 : Hp[0];
+    int accept = 0;
+    for (int k = lane; k < count; k += 64) sord[k] = ord[k];
+    __syncthreads();
 
     if (!first) {
-        // curvature pair of the step just taken
-        float a[2] = {0.f, 0.f};
-        for (int i = tid; i < n; i += LB_THREADS) {
-            const float y = g[i] - prev_g[i], s = d[i] * t;
-            a[0] = fmaf(y, s, a[0]);
-            a[1] = fmaf(y, y, a[1]);
+        // fold the per-chunk partials of every live row and of the candidate, in chunk order
+        for (int r = lane; r <= count; r += 64) {
+            const int slot = r < count ? sord[r] : cand;
+            double a[LB_NDOT] = {0, 0, 0, 0, 0};
+            for (int ch = 0; ch < L.nchunk; ++ch)
+                for (int k = 0; k < LB_NDOT; ++k) a[k] += part[(int64_t(slot) * L.nchunk + ch) * LB_NDOT + k];
+            for (int k = 0; k < LB_NDOT; ++k) pd[r * LB_NDOT + k] = a[k];
         }
-        block_reduce<2, 0>(a, dummy, red);
-        const float ys = a[0];
-        if (ys > 1e-10f) {      // same value on every thread
-            int slot;
+        __syncthreads();
+        const double ys = pd[count * LB_NDOT + 2], yy = pd[count * LB_NDOT + 4];
+        accept = (float)ys > 1e-10f;
+        // s_j.g and y_j.g of the live rows
+        for (int r = lane; r < count; r += 64) {
+            b[sord[r]] = pd[r * LB_NDOT + 0];
+            c[sord[r]] = pd[r * LB_NDOT + 1];
+        }
+        if (accept) {
+            for (int r = lane; r < count; r += 64) {
+                const int j = sord[r];
+                SY[int64_t(j) * slots + cand] = pd[r * LB_NDOT + 2];
+                SY[int64_t(cand) * slots + j] = pd[r * LB_NDOT + 3];
+                YY[int64_t(j) * slots + cand] = pd[r * LB_NDOT + 4];
+                YY[int64_t(cand) * slots + j] = pd[r * LB_NDOT + 4];
+            }
+            if (lane == 0) {
+                SY[int64_t(cand) * slots + cand] = ys;
+                YY[int64_t(cand) * slots + cand] = yy;
+                ro[cand] = 1.0 / ys;
+                b[cand] = pd[count * LB_NDOT + 0];
+                c[cand] = pd[count * LB_NDOT + 1];
+            }
+            H = ys / yy;
+            __syncthreads();
+            // history bookkeeping: drop the oldest pair when full; its slot becomes the next free one
+            int freed;
             if (count == hist) {
-                slot = head;                     // overwrite the oldest pair
-                head = (head + 1) % hist;
+                freed = sord[0];
+                __syncthreads();
+                int keep[(LB_MAX_HISTORY + 63) / 64];
+                int m = 0;
+                for (int k = lane; k + 1 < count; k += 64) keep[m++] = sord[k + 1];
+                __syncthreads();
+                m = 0;
+                for (int k = lane; k + 1 < count; k += 64) sord[k] = keep[m++];
+                if (lane == 0) sord[count - 1] = cand;
             } else {
-                slot = (head + count) % hist;
+                if (lane == 0) sord[count] = cand;
                 ++count;
+                freed = count;            // slots are handed out in order 0,1,2,... until the ring is full
             }
-            float *Ys = Y + int64_t(slot) * np, *Ss = S + int64_t(slot) * np;
-            for (int i = tid; i < n; i += LB_THREADS) {
-                Ys[i] = g[i] - prev_g[i];
-                Ss[i] = d[i] * t;
-            }
-            if (tid == 0) ro[slot] = 1.f / ys;
-            Hd = ys / a[1];
-            __syncthreads();                     // ro[slot] visible to the whole workgroup
+            cand = freed;
         }
+        __syncthreads();
     }
 
-    // q = -g, fused with the first dot product of the first loop
-    float dot[1] = {0.f};
-    {
-        const float *Sn = count > 0 ? S + int64_t((head + count - 1) % hist) * np : nullptr;
-        for (int i = tid; i < n; i += LB_THREADS) {
-            const float qi = -g[i];
-            q[i] = qi;
-            if (Sn) dot[0] = fmaf(Sn[i], qi, dot[0]);
+    // two-loop recursion on scalars.  Logical k = 0 oldest .. count-1 newest, j = sord[k].
+    const bool staged = ldsn >= count && ldsn > 0;
+    if (staged)
+        for (int idx = lane; idx < count * count; idx += 64) {
+            const int k = idx / count, m = idx - k * count;
+            SYl[k * ldsn + m] = SY[int64_t(sord[k]) * slots + sord[m]];
         }
-        if (count > 0) block_reduce<1, 0>(dot, dummy, red);
+    for (int k = lane; k < count; k += 64) {
+        rok[k] = ro[sord[k]];
+        bk[k] = b[sord[k]];
     }
-    // first loop, newest -> oldest: al_k = ro_k s_k.q ; q -= al_k y_k   (the pass that updates q also
-    // accumulates the next dot product: s_{k-1}.q, or y_0.(H q) when the loop ends)
+    __syncthreads();
+    //   al_k = ro_j ( -s_j.g - sum_{m>k} al_m s_j.y_m )
     for (int k = count - 1; k >= 0; --k) {
-        const int slot = (head + k) % hist;
-        const float al = dot[0] * ro[slot];
-        if (tid == 0) al_s[k] = al;
-        const float *Yk = Y + int64_t(slot) * np;
-        const float *nxt = k > 0 ? S + int64_t((head + k - 1) % hist) * np : Y + int64_t(head % hist) * np;
-        const float scale = k > 0 ? 1.f : Hd;
-        float nd[1] = {0.f};
-        for (int i = tid; i < n; i += LB_THREADS) {
-            const float qi = fmaf(-al, Yk[i], q[i]);
-            q[i] = qi;
-            nd[0] = fmaf(nxt[i], qi * scale, nd[0]);
-        }
-        block_reduce<1, 0>(nd, dummy, red);
-        dot[0] = nd[0];
+        const int j = sord[k];
+        double a = 0.0;
+        if (staged)
+            for (int m = k + 1 + lane; m < count; m += 64) a = fma(al[m], SYl[k * ldsn + m], a);
+        else
+            for (int m = k + 1 + lane; m < count; m += 64) a = fma(al[m], SY[int64_t(j) * slots + sord[m]], a);
+        a = wave_sum(a);
+        if (lane == 0) al[k] = rok[k] * (-bk[k] - a);
+        __syncthreads();
     }
-    __syncthreads();    // al_s complete
-    // r = H q ; second loop, oldest -> newest: be_k = ro_k y_k.r ; r += (al_k - be_k) s_k
-    for (int i = tid; i < n; i += LB_THREADS) q[i] *= Hd;
+    //   be_k = ro_j y_j.r_k,  r_k = H(-g - sum_m al_m y_m) + sum_{m<k} cc_m s_m,  cc_k = al_k - be_k
+    //   the y_j.(H q) part does not depend on earlier steps: all k in parallel first
+    for (int k = lane; k < count; k += 64) {
+        const int j = sord[k];
+        double a = 0.0;
+        for (int m = 0; m < count; ++m) a = fma(al[m], YY[int64_t(j) * slots + sord[m]], a);
+        Ak[k] = H * (-c[j] - a);
+    }
+    __syncthreads();
     for (int k = 0; k < count; ++k) {
-        const int slot = (head + k) % hist;
-        const float coef = al_s[k] - dot[0] * ro[slot];
-        const float *Sk = S + int64_t(slot) * np;
-        const float *nxt = k + 1 < count ? Y + int64_t((head + k + 1) % hist) * np : nullptr;
-        float nd[1] = {0.f};
-        for (int i = tid; i < n; i += LB_THREADS) {
-            const float ri = fmaf(coef, Sk[i], q[i]);
-            q[i] = ri;
-            if (nxt) nd[0] = fmaf(nxt[i], ri, nd[0]);
-        }
-        if (nxt) {
-            block_reduce<1, 0>(nd, dummy, red);
-            dot[0] = nd[0];
-        }
+        const int j = sord[k];
+        double e = 0.0;
+        if (staged)
+            for (int m = lane; m < k; m += 64) e = fma(cc[m], SYl[m * ldsn + k], e);
+        else
+            for (int m = lane; m < k; m += 64) e = fma(cc[m], SY[int64_t(sord[m]) * slots + j], e);
+        e = wave_sum(e);
+        if (lane == 0) cc[k] = al[k] - rok[k] * (Ak[k] + e);
+        __syncthreads();
     }
-    // d = r, g_prev = g, and the scalars the host needs
-    float s2[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
-    for (int i = tid; i < n; i += LB_THREADS) {
-        const float di = q[i], gi = g[i];
+    for (int k = lane; k < count; k += 64) {
+        coefY[k] = -H * al[k];
+        coefS[k] = cc[k];
+        ord[k] = sord[k];
+    }
+    if (lane == 0) {
+        coefY[slots] = -H;     // coefficient of g
+        hdr[0] = count;
+        hdr[1] = cand;
+        hdr[2] = accept;
+        Hp[0] = H;
+    }
+}
+
+// ---- k_combine: grid (ncomb), one element per thread.  `newest` = physical slot of the just-accepted pair
+// (its values are still in registers here; this kernel stores them)
+__global__ __launch_bounds__(LB_BLOCK) void k_combine(char *__restrict__ ws, int n, int hist, const float *__restrict__ g,
+                                                      float *__restrict__ d, float t, int first) {
+    __shared__ double red[(LB_BLOCK / 64) * 4];
+    __shared__ double cY[LB_MAX_HISTORY], cS[LB_MAX_HISTORY];
+    __shared__ int sord[LB_MAX_HISTORY];
+    const LbLayout L = lb_layout(n, hist);
+    const int *hdr = at<int>(ws, L.hdr);
+    const int *ord = at<int>(ws, L.ord);
+    const int count = hdr[0], accept = hdr[2];
+    const double *coefY = at<double>(ws, L.coefY), *coefS = at<double>(ws, L.coefS);
+    for (int k = threadIdx.x; k < count; k += LB_BLOCK) {
+        cY[k] = coefY[k];
+        cS[k] = coefS[k];
+        sord[k] = ord[k];
+    }
+    __syncthreads();
+    const int newest = accept ? sord[count - 1] : -1;
+    const int stored = accept ? count - 1 : count;      // pairs whose rows are in memory (the newest one is not yet)
+    const double cG = coefY[L.slots];
+    float *prev_g = at<float>(ws, L.prev_g);
+    float *S = at<float>(ws, L.S), *Y = at<float>(ws, L.Y);
+    double st[4] = {0, 0, 0, 0};    // g.d, sum|g|, max|d|, max|g|
+    const int i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    if (i < n) {
+        const float gi = g[i];
+        const float yc = first ? 0.f : gi - prev_g[i];
+        const float sc = first ? 0.f : d[i] * t;
+        double acc = cG * (double)gi;
+        int k = 0;
+        for (; k + 4 <= stored; k += 4) {               // 8 independent loads in flight
+            float yv[4], sv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t row = int64_t(sord[k + u]) * L.np + i;
+                yv[u] = Y[row];
+                sv[u] = S[row];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc = fma(cY[k + u], (double)yv[u], acc);
+                acc = fma(cS[k + u], (double)sv[u], acc);
+            }
+        }
+        for (; k < stored; ++k) {
+            const int64_t row = int64_t(sord[k]) * L.np + i;
+            acc = fma(cY[k], (double)Y[row], acc);
+            acc = fma(cS[k], (double)S[row], acc);
+        }
+        if (newest >= 0) {
+            acc = fma(cY[count - 1], (double)yc, acc);
+            acc = fma(cS[count - 1], (double)sc, acc);
+            Y[int64_t(newest) * L.np + i] = yc;
+            S[int64_t(newest) * L.np + i] = sc;
+        }
+        const float di = (float)acc;
         d[i] = di;
         prev_g[i] = gi;
-        s2[0] = fmaf(gi, di, s2[0]);
-        s2[1] += fabsf(gi);
-        m2[0] = fmaxf(m2[0], fabsf(di));
-        m2[1] = fmaxf(m2[1], fabsf(gi));
+        st[0] = (double)gi * (double)di;
+        st[1] = fabs((double)gi);
+        st[2] = fabs((double)di);
+        st[3] = fabs((double)gi);
     }
-    block_reduce<2, 2>(s2, m2, red);
-    if (tid == 0) {
-        ws[0] = (float)count;
-        ws[1] = (float)head;
-        ws[2] = Hd;
-        stats[0] = s2[0];         // g.d
-        stats[1] = s2[1];         // sum |g|
-        stats[2] = m2[0];         // max |d|
-        stats[3] = m2[1];         // max |g|
-        stats[4] = (float)count;
-        stats[5] = Hd;
-        stats[6] = 0.f;
-        stats[7] = 0.f;
+    block_reduce<2, 2>(st, red);
+    if (threadIdx.x == 0) {
+        double *p = at<double>(ws, L.spart) + int64_t(blockIdx.x) * 4;
+        p[0] = st[0]; p[1] = st[1]; p[2] = st[2]; p[3] = st[3];
     }
+}
+
+// one wave: lane l folds partials l, l+64, ... in order, then the lanes are folded in a fixed tree
+__global__ __launch_bounds__(64) void k_stats(const char *__restrict__ ws, int n, int hist, float *__restrict__ stats) {
+    const LbLayout L = lb_layout(n, hist);
+    const double *p = reinterpret_cast<const double *>(ws + L.spart);
+    double a0 = 0, a1 = 0, m2 = 0, m3 = 0;
+    for (int ch = threadIdx.x; ch < L.ncomb; ch += 64) {
+        a0 += p[ch * 4 + 0];
+        a1 += p[ch * 4 + 1];
+        m2 = fmax(m2, p[ch * 4 + 2]);
+        m3 = fmax(m3, p[ch * 4 + 3]);
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    m2 = wave_max(m2);
+    m3 = wave_max(m3);
+    if (threadIdx.x != 0) return;
+    const int *hdr = reinterpret_cast<const int *>(ws + L.hdr);
+    stats[0] = (float)a0;           // g.d
+    stats[1] = (float)a1;           // sum |g|
+    stats[2] = (float)m2;           // max |d|
+    stats[3] = (float)m3;           // max |g|
+    stats[4] = (float)hdr[0];       // pairs held
+    stats[5] = (float)reinterpret_cast<const double *>(ws + L.H)[0];
+    stats[6] = (float)hdr[2];       // the last pair was accepted
+    stats[7] = 0.f;
 }
 
 // out = [loss, g.d, max|g|, sum|g|] after one closure evaluation of the line search
-__global__ __launch_bounds__(LB_THREADS) void k_lbfgs_eval_stats(const float *__restrict__ g, const float *__restrict__ d,
-                                                                 int n, const float *__restrict__ loss,
-                                                                 float *__restrict__ out) {
-    __shared__ float red[LB_WAVES * 3];
-    float s[2] = {0.f, 0.f}, m[1] = {0.f};
-    for (int i = threadIdx.x; i < n; i += LB_THREADS) {
+__global__ __launch_bounds__(1024) void k_lbfgs_eval_stats(const float *__restrict__ g, const float *__restrict__ d, int n,
+                                                           const float *__restrict__ loss, float *__restrict__ out) {
+    __shared__ double red[16 * 3];
+    double s0 = 0, s1 = 0, m = 0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
         const float gi = g[i];
-        s[0] = fmaf(gi, d[i], s[0]);
-        s[1] += fabsf(gi);
-        m[0] = fmaxf(m[0], fabsf(gi));
+        s0 = fma((double)gi, (double)d[i], s0);
+        s1 += fabs((double)gi);
+        m = fmax(m, fabs((double)gi));
     }
-    block_reduce<2, 1>(s, m, red);
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    m = wave_max(m);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[w * 3 + 0] = s0;
+        red[w * 3 + 1] = s1;
+        red[w * 3 + 2] = m;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) {
+            s0 += red[i * 3 + 0];
+            s1 += red[i * 3 + 1];
+            m = fmax(m, red[i * 3 + 2]);
+        }
         out[0] = loss ? loss[0] : 0.f;
-        out[1] = s[0];
-        out[2] = m[0];
-        out[3] = s[1];
+        out[1] = (float)s0;
+        out[2] = (float)m;
+        out[3] = (float)s1;
     }
+}
+
+inline bool bad_sizes(int64_t n, int32_t history) {
+    return n <= 0 || history <= 0 || history > LB_MAX_HISTORY || n > (int64_t(1) << 24);
 }
 
 }  // namespace
@@ -229,24 +435,32 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_eval_stats(const float *__
 extern "C" {
 
 int64_t pinn_lbfgs_workspace_floats(int64_t n, int32_t history) {
-    if (n <= 0 || history <= 0 || history > LB_MAX_HISTORY || n > (int64_t(1) << 24)) return PINN_ERR_INVALID_DESC;
-    return lb_layout(n, history).total;
+    if (bad_sizes(n, history)) return PINN_ERR_INVALID_DESC;
+    return lb_layout(n, history).total / 4;
 }
 
 int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const float *g, float *d, float t,
                          int32_t first, float *stats8, void *stream) {
     if (!workspace || !g || !d || !stats8) return PINN_ERR_NULL;
-    if (n <= 0 || history <= 0 || history > LB_MAX_HISTORY || n > (int64_t(1) << 24)) return PINN_ERR_INVALID_DESC;
-    hipLaunchKernelGGL(k_lbfgs_direction, dim3(1), dim3(LB_THREADS), 0, (hipStream_t)stream, workspace, (int)n,
-                       (int)history, g, d, t, (int)first, stats8);
+    if (bad_sizes(n, history)) return PINN_ERR_INVALID_DESC;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return PINN_ERR_INVALID_DESC;
+    const LbLayout L = lb_layout(n, history);
+    char *ws = reinterpret_cast<char *>(workspace);
+    hipStream_t s = (hipStream_t)stream;
+    if (!first)
+        hipLaunchKernelGGL(k_dots, dim3(L.nchunk, L.slots), dim3(LB_BLOCK), 0, s, ws, (int)n, (int)history, g, d, t);
+    const int ldsn = (history + 1) * (history + 1) * 8 <= 40 * 1024 ? history + 1 : 0;   // static LDS of k_scalars: 22 KB
+    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), size_t(ldsn) * ldsn * 8, s, ws, (int)n, (int)history, (int)first,
+                       ldsn);
+    hipLaunchKernelGGL(k_combine, dim3(L.ncomb), dim3(LB_BLOCK), 0, s, ws, (int)n, (int)history, g, d, t, (int)first);
+    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, s, ws, (int)n, (int)history, stats8);
     return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 
 int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float *loss, float *out4, void *stream) {
     if (!g || !d || !out4) return PINN_ERR_NULL;
     if (n <= 0 || n > (int64_t(1) << 24)) return PINN_ERR_INVALID_DESC;
-    hipLaunchKernelGGL(k_lbfgs_eval_stats, dim3(1), dim3(LB_THREADS), 0, (hipStream_t)stream, g, d, (int)n, loss,
-                       out4);
+    hipLaunchKernelGGL(k_lbfgs_eval_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, d, (int)n, loss, out4);
     return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 

@@ -116,6 +116,10 @@ class LBFGS(torch.optim.Optimizer):
         self._g.zero_()
         self._attach_grads()
 
+    def flat_grad(self):
+        """The static flat gradient buffer `.grad` are views of (what a captured closure zeroes)."""
+        return self._g
+
     def _gather(self):
         """Flat gradient after a closure; copies only what a foreign zero_grad()/backward re-pointed."""
         off = 0

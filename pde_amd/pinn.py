@@ -334,7 +334,11 @@ class PhysicsInformedNN:
             self.optimizer_LBFGS.zero_grad()
             return self.backward()
         if LBFGS_max_iter > 0:
-            self.optimizer_LBFGS.step(LBFGS_callback)
+            closure = LBFGS_callback
+            if self.use_hip_graph and self.group is None and torch.device(self.device).type == "cuda" \
+                    and hasattr(self.optimizer_LBFGS, "flat_grad"):
+                closure = self._graph_closure() or LBFGS_callback
+            self.optimizer_LBFGS.step(closure)
         elapsed = time.time() - start_time
         if self.logfilename is not None:
             self.writer.write('Training time: %.4f' % (elapsed))
@@ -388,6 +392,39 @@ class PhysicsInformedNN:
         self.graph_stats = {"replays": n_rep, "seconds": time.time() - t_rep}
         self._adam_graph = graph                        # keep the captured buffers alive with the model
         return done
+
+    def _graph_closure(self):
+        """The L-BFGS closure (zero the flat gradient, the loss terms, loss.backward()) captured once
+        into a HIP graph and replayed per evaluation: the line search moves the weights in place, so
+        every address the graph holds stays valid.  Needs pde_amd.lbfgs.LBFGS (its `.grad` are views
+        of one static buffer).  Returns None when the capture fails."""
+        opt = self.optimizer_LBFGS
+        try:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):                      # eager: allocates the kernels' workspaces
+                    opt.zero_grad()
+                    self._loss_terms()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad()
+            with torch.cuda.graph(graph):
+                opt.flat_grad().zero_()
+                terms = self._loss_terms()
+        except Exception as ex:                         # noqa: BLE001 - any capture problem -> eager closure
+            print("HIP-graph capture of the L-BFGS closure failed (%s); continuing eagerly" % (ex,))
+            torch.cuda.synchronize(self.device)
+            return None
+        self._lbfgs_graph = graph
+
+        def closure():
+            graph.replay()
+            self._log_terms(terms)
+            self.iter += 1
+            return terms["loss"]
+        return closure
 
     # ------------------------------------------------------------------ io
     def load_model(self, filename):

@@ -14,7 +14,7 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize("n,hist", [(7851, 5), (30802, 50), (37, 3), (1024, 1)])
+@pytest.mark.parametrize("n,hist", [(7851, 5), (30802, 50), (37, 3), (1024, 1), (12737, 150)])
 def test_direction_kernel_matches_float64_two_loop(n, hist):
     """A synthetic quadratic-like sequence (g_{k+1} = g_k + A-ish * step) drives both implementations
     through more steps than the history holds (ring wrap) and through rejected pairs (y.s <= 1e-10).
@@ -59,8 +59,9 @@ def test_lbfgs_entry_points_reject_bad_arguments():
     lib = load_library()
     assert lib.pinn_lbfgs_workspace_floats(0, 5) < 0
     assert lib.pinn_lbfgs_workspace_floats(100, 0) < 0
-    assert lib.pinn_lbfgs_workspace_floats(100, 513) < 0
-    assert lib.pinn_lbfgs_workspace_floats(100, 4) == 16 + 4 + 100 + 100 + 2 * 4 * 100
+    assert lib.pinn_lbfgs_workspace_floats(100, 257) < 0
+    small, big = lib.pinn_lbfgs_workspace_floats(100, 4), lib.pinn_lbfgs_workspace_floats(30802, 50)
+    assert small > 2 * 5 * 100 and big > 2 * 51 * 30802 and big < 4 * 51 * 30802
     assert lib.pinn_lbfgs_direction(None, 100, 4, None, None, 1.0, 1, None, None) == -4
     assert lib.pinn_lbfgs_eval_stats(None, None, 100, None, None, None) == -4
 
@@ -104,3 +105,17 @@ def test_long_device_lbfgs_run_converges():
     m.optimizer_LBFGS.zero_grad()
     l1 = m.backward().item()
     assert l1 < 0.2 * l0, (l0, l1)
+
+
+def test_graph_replayed_closure_matches_eager_closure():
+    """use_hip_graph: the L-BFGS closure replayed from a captured HIP graph runs the same kernels on
+    the same buffers as the eager closure -> identical evaluation count, weights equal to rounding."""
+    res = {}
+    for graph in (False, True):
+        m = _burgers_model("device")
+        m.use_hip_graph = graph
+        m.train(0, LBFGS_max_iter=10)
+        res[graph] = (m.iter, m.dnn.flat_theta().detach().cpu().double().numpy().copy())
+        assert hasattr(m, "_lbfgs_graph") == graph
+    assert res[True][0] == res[False][0]
+    assert _rel(res[True][1], res[False][1]) < 1e-3

@@ -25,11 +25,11 @@ CASES = {
 }
 
 
-def run(case, impl, n, iters):
+def run(case, impl, n, iters, graph=False):
     c = CASES[case]
     torch.manual_seed(1234)
     base = getattr(scripts, c["family"]).PI.PhysicsInformedNN
-    cls = type("M", (base,), {"lbfgs_impl": impl})
+    cls = type("M", (base,), {"lbfgs_impl": impl, "use_hip_graph": graph})
     lb, ub = np.array(c["lb"]), np.array(c["ub"])
     m = cls(c["layers"], lb, ub)
     rng = np.random.default_rng(1)
@@ -68,5 +68,8 @@ if __name__ == "__main__":
     a = ap.parse_args()
     for case in a.cases.split(","):
         r = {impl: run(case, impl, a.n, a.iters) for impl in ("torch", "device")}
-        print(json.dumps({"case": case, "n_f": a.n, "torch": r["torch"], "device": r["device"],
-                          "speedup_evals_per_s": r["device"]["evals_per_s"] / r["torch"]["evals_per_s"]}), flush=True)
+        r["device+graph"] = run(case, "device", a.n, a.iters, graph=True)
+        print(json.dumps({"case": case, "n_f": a.n, **r,
+                          "speedup_evals_per_s": r["device"]["evals_per_s"] / r["torch"]["evals_per_s"],
+                          "speedup_graph_evals_per_s": r["device+graph"]["evals_per_s"] / r["torch"]["evals_per_s"]}),
+              flush=True)
