@@ -50,22 +50,43 @@ __device__ __forceinline__ float fast_tanh(float x)
 // ---- tanh on a jet -----------------------------------------------------------
 // y' = (1-y^2) z'  =>  k y_k = sum_{j=1..k} j z_j w_{k-j},  w = 1 - y*y.
 // z, y: [J] (x orders then t tangents);  w: [K+1].
+//
+// Operation counts matter here (the kernels are instruction-issue bound): the convolution
+// w_k = -sum_i y_i y_{k-i} is taken over HALF its terms with pre-doubled factors
+// (ceil((k+1)/2) FMAs instead of k+1), the weights j z_j are formed once, and w_K — which no
+// y_k uses unless a t-tangent of that order is carried — is skipped.
+template <int K, int KT>
+__device__ __forceinline__ void w_order(const float *y, const float (&ym2)[K / 2 + 1], int k, float &wk)
+{
+    // w_k = sum_{i < k/2 (strict half)} (-2 y_i) y_{k-i}  [ - y_{k/2}^2 when k is even ]
+    float q = ym2[0] * y[k];
+#pragma unroll
+    for (int i = 1; 2 * i < k; ++i) q = fmaf(ym2[i], y[k - i], q);
+    if ((k & 1) == 0) q = fmaf(-y[k / 2], y[k / 2], q);
+    wk = q;
+}
+
 template <int K, int KT>
 __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float (&y)[K + 1 + KT],
                                              float (&w)[K + 1])
 {
+    constexpr int KW0 = KT - 1 > K - 1 ? KT - 1 : K - 1;
+    constexpr int KW = KW0 < K ? KW0 : K;   // highest w order anything reads: y_k uses w_0..w_{k-1}, t-tangents w_0..w_{KT-1}
     y[0] = fast_tanh(z[0]);   // branch-free: keeps a whole tile's tanh work in one scheduling region
     w[0] = fmaf(-y[0], y[0], 1.0f);
+    float zs[K + 1], ym2[K / 2 + 1];
+#pragma unroll
+    for (int j = 1; j <= K; ++j) zs[j] = (float)j * z[j];
+    ym2[0] = -2.0f * y[0];
 #pragma unroll
     for (int k = 1; k <= K; ++k) {
-        float s = 0.0f;
+        float s = zs[1] * w[k - 1];
 #pragma unroll
-        for (int j = 1; j <= k; ++j) s = fmaf((float)j * z[j], w[k - j], s);
+        for (int j = 2; j <= k; ++j) s = fmaf(zs[j], w[k - j], s);
         y[k] = s * (1.0f / (float)k);
-        float q = 0.0f;
-#pragma unroll
-        for (int i = 0; i <= k; ++i) q = fmaf(y[i], y[k - i], q);
-        w[k] = -q;
+        if (k <= K / 2) ym2[k] = -2.0f * y[k];
+        if (k <= KW) w_order<K, KT>(y, ym2, k, w[k]);
+        else w[k] = 0.0f;     // never read
     }
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -80,14 +101,12 @@ __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float
 template <int K>
 __device__ __forceinline__ void w_from_y(const float *y, float (&w)[K + 1])
 {
+    float ym2[K / 2 + 1];
+#pragma unroll
+    for (int k = 0; k <= K / 2; ++k) ym2[k] = -2.0f * y[k];
     w[0] = fmaf(-y[0], y[0], 1.0f);
 #pragma unroll
-    for (int k = 1; k <= K; ++k) {
-        float q = 0.0f;
-#pragma unroll
-        for (int i = 0; i <= k; ++i) q = fmaf(y[i], y[k - i], q);
-        w[k] = -q;
-    }
+    for (int k = 1; k <= K; ++k) w_order<K, 0>(y, ym2, k, w[k]);
 }
 
 // reverse of tanh_jet_fwd: yb (adjoint of y, modified in place) -> zb.
@@ -96,9 +115,12 @@ __device__ __forceinline__ void tanh_jet_bwd(const float (&z)[K + 1 + KT], const
                                              const float (&w)[K + 1], float (&yb)[K + 1 + KT],
                                              float (&zb)[K + 1 + KT])
 {
-    float wb[K + 1];
+    // wb: adjoint of w; zsb: adjoint of the weighted coefficient zs_j = j z_j (scaled by j at the end)
+    float wb[K + 1], zs[K + 1], zsb[K + 1];
 #pragma unroll
-    for (int k = 0; k <= K; ++k) { wb[k] = 0.0f; zb[k] = 0.0f; }
+    for (int k = 0; k <= K; ++k) { wb[k] = 0.0f; zsb[k] = 0.0f; }
+#pragma unroll
+    for (int j = 1; j <= K; ++j) zs[j] = (float)j * z[j];
 #pragma unroll
     for (int k = 0; k < KT; ++k) zb[K + 1 + k] = 0.0f;
 #pragma unroll
@@ -111,19 +133,23 @@ __device__ __forceinline__ void tanh_jet_bwd(const float (&z)[K + 1 + KT], const
     }
 #pragma unroll
     for (int k = K; k >= 1; --k) {
-        const float m2 = -2.0f * wb[k];
+        // wb[k] is still exactly zero when nothing read w_k: k = K with no t-tangent of that order
+        if (k < K || KT > K) {
+            const float m2 = -2.0f * wb[k];
 #pragma unroll
-        for (int m = 0; m <= k; ++m) yb[m] = fmaf(m2, y[k - m], yb[m]);
+            for (int m = 0; m <= k; ++m) yb[m] = fmaf(m2, y[k - m], yb[m]);
+        }
         const float g = yb[k] * (1.0f / (float)k);
 #pragma unroll
         for (int j = 1; j <= k; ++j) {
-            const float gj = g * (float)j;
-            zb[j] = fmaf(gj, w[k - j], zb[j]);
-            wb[k - j] = fmaf(gj, z[j], wb[k - j]);
+            zsb[j] = fmaf(g, w[k - j], zsb[j]);
+            wb[k - j] = fmaf(g, zs[j], wb[k - j]);
         }
     }
     yb[0] = fmaf(-2.0f * wb[0], y[0], yb[0]);
     zb[0] = yb[0] * w[0];
+#pragma unroll
+    for (int j = 1; j <= K; ++j) zb[j] = (float)j * zsb[j];
 }
 
 __host__ __device__ constexpr float factorial(int k)
