@@ -66,7 +66,9 @@ __device__ __forceinline__ void w_order(const float *y, const float (&ym2)[K / 2
     wk = q;
 }
 
-template <int K, int KT>
+// ZN / ZTN: the input jet is structurally zero above x-order ZN and in t-tangents of order >= ZTN
+// (first layer: z = W0 [x,t] + b is affine in x and t, so ZN = 1, ZTN = 1); those terms are not issued.
+template <int K, int KT, int ZN = K, int ZTN = KT>
 __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float (&y)[K + 1 + KT],
                                              float (&w)[K + 1])
 {
@@ -76,13 +78,13 @@ __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float
     w[0] = fmaf(-y[0], y[0], 1.0f);
     float zs[K + 1], ym2[K / 2 + 1];
 #pragma unroll
-    for (int j = 1; j <= K; ++j) zs[j] = (float)j * z[j];
+    for (int j = 1; j <= ZN; ++j) zs[j] = (float)j * z[j];
     ym2[0] = -2.0f * y[0];
 #pragma unroll
     for (int k = 1; k <= K; ++k) {
-        float s = zs[1] * w[k - 1];
+        float s = ZN >= 1 ? zs[ZN >= 1 ? 1 : 0] * w[k - 1] : 0.0f;
 #pragma unroll
-        for (int j = 2; j <= k; ++j) s = fmaf(zs[j], w[k - j], s);
+        for (int j = 2; j <= (k < ZN ? k : ZN); ++j) s = fmaf(zs[j], w[k - j], s);
         y[k] = s * (1.0f / (float)k);
         if (k <= K / 2) ym2[k] = -2.0f * y[k];
         if (k <= KW) w_order<K, KT>(y, ym2, k, w[k]);
@@ -92,7 +94,7 @@ __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float
     for (int k = 0; k < KT; ++k) {
         float s = 0.0f;
 #pragma unroll
-        for (int j = 0; j <= k; ++j) s = fmaf(w[j], z[K + 1 + k - j], s);
+        for (int j = (k - ZTN + 1 > 0 ? k - ZTN + 1 : 0); j <= k; ++j) s = fmaf(w[j], z[K + 1 + k - j], s);
         y[K + 1 + k] = s;
     }
 }
@@ -109,8 +111,9 @@ __device__ __forceinline__ void w_from_y(const float *y, float (&w)[K + 1])
     for (int k = 1; k <= K; ++k) w_order<K, 0>(y, ym2, k, w[k]);
 }
 
-// reverse of tanh_jet_fwd: yb (adjoint of y, modified in place) -> zb.
-template <int K, int KT>
+// reverse of tanh_jet_fwd: yb (adjoint of y, modified in place) -> zb.  With ZN < K / ZTN < KT the adjoints
+// of the structurally-zero inputs are not formed (returned as 0).
+template <int K, int KT, int ZN = K, int ZTN = KT>
 __device__ __forceinline__ void tanh_jet_bwd(const float (&z)[K + 1 + KT], const float (&y)[K + 1 + KT],
                                              const float (&w)[K + 1], float (&yb)[K + 1 + KT],
                                              float (&zb)[K + 1 + KT])
@@ -120,13 +123,13 @@ __device__ __forceinline__ void tanh_jet_bwd(const float (&z)[K + 1 + KT], const
 #pragma unroll
     for (int k = 0; k <= K; ++k) { wb[k] = 0.0f; zsb[k] = 0.0f; }
 #pragma unroll
-    for (int j = 1; j <= K; ++j) zs[j] = (float)j * z[j];
+    for (int j = 1; j <= ZN; ++j) zs[j] = (float)j * z[j];
 #pragma unroll
     for (int k = 0; k < KT; ++k) zb[K + 1 + k] = 0.0f;
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
 #pragma unroll
-        for (int j = 0; j <= k; ++j) {
+        for (int j = (k - ZTN + 1 > 0 ? k - ZTN + 1 : 0); j <= k; ++j) {
             wb[j] = fmaf(yb[K + 1 + k], z[K + 1 + k - j], wb[j]);
             zb[K + 1 + k - j] = fmaf(yb[K + 1 + k], w[j], zb[K + 1 + k - j]);
         }
@@ -141,7 +144,7 @@ __device__ __forceinline__ void tanh_jet_bwd(const float (&z)[K + 1 + KT], const
         }
         const float g = yb[k] * (1.0f / (float)k);
 #pragma unroll
-        for (int j = 1; j <= k; ++j) {
+        for (int j = 1; j <= (k < ZN ? k : ZN); ++j) {
             zsb[j] = fmaf(g, w[k - j], zsb[j]);
             wb[k - j] = fmaf(g, zs[j], wb[k - j]);
         }
@@ -149,7 +152,7 @@ __device__ __forceinline__ void tanh_jet_bwd(const float (&z)[K + 1 + KT], const
     yb[0] = fmaf(-2.0f * wb[0], y[0], yb[0]);
     zb[0] = yb[0] * w[0];
 #pragma unroll
-    for (int j = 1; j <= K; ++j) zb[j] = (float)j * zsb[j];
+    for (int j = 1; j <= K; ++j) zb[j] = j <= ZN ? (float)j * zsb[j] : 0.0f;
 }
 
 __host__ __device__ constexpr float factorial(int k)

@@ -262,6 +262,8 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
     constexpr bool TAIL = C::TAIL, WGLOBAL = C::WGLOBAL;
     constexpr int MFMA_BLOCK = C::BLOCK, MFMA_WAVES = C::WAVES, STG = C::STG;
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
+    // the first layer's pre-activation is affine in (x, t): nothing above x-order 1 / t-tangent order 0
+    constexpr int ZN0 = K >= 1 ? 1 : 0, ZTN0 = KT >= 1 ? 1 : 0;
     constexpr int TILE = 256;                      // floats of one 16x16 stash image
     constexpr int ZY = NT * J * TILE;              // main z (or y) images of one hidden layer
     constexpr int TS = ((RR * J * 16 + 63) / 64) * 64;  // tail z (or y) of one hidden layer: [e][k][p]
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                 for (int r = 0; r < 4; ++r) {
                     float z[J], y[J], w[K + 1];
                     z0_main(w0, r, z);
-                    tanh_jet_fwd<K, KT>(z, y, w);
+                    tanh_jet_fwd<K, KT, ZN0, ZTN0>(z, y, w);
 #pragma unroll
                     for (int j = 0; j < J; ++j) pin(y[j]);
                     if (topl) {
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                 for (int e = 0; e < R; ++e) {
                     float z[J], y[J], w[K + 1];
                     z0_tail(e, z);
-                    tanh_jet_fwd<K, KT>(z, y, w);
+                    tanh_jet_fwd<K, KT, ZN0, ZTN0>(z, y, w);
                     if (topl) {
                         out_acc_tail(e, y);
 #pragma unroll
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                         }
 #pragma unroll
                         for (int j = 0; j < J; ++j) yb[j] = A[T][j][r];
-                        tanh_jet_fwd<K, KT>(z, y, w);
+                        tanh_jet_fwd<K, KT, FIRST ? ZN0 : K, FIRST ? ZTN0 : KT>(z, y, w);
                         if (TAIL) {
                             // tail rows of Wb_l against this neuron of y_hl (Zbtail of layer l: parked in LDS)
 #pragma unroll
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                                 if (p == 0) PINN_ADD_S(&gtr[e * W + n], v);
                             }
                         }
-                        tanh_jet_bwd<K, KT>(z, y, w, yb, zb);
+                        tanh_jet_bwd<K, KT, FIRST ? ZN0 : K, FIRST ? ZTN0 : KT>(z, y, w, yb, zb);
 #pragma unroll
                         for (int j = 0; j < J; ++j) pin(zb[j]);
 #pragma unroll
@@ -1073,11 +1075,13 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                     if (hl > 0) {
 #pragma unroll
                         for (int j = 0; j < J; ++j) z[j] = sb_load1(srs, vp, zs + 2 * ZY + (e * J + j) * 16);
+                        tanh_jet_fwd<K, KT>(z, y, w);
+                        tanh_jet_bwd<K, KT>(z, y, w, At[e], zb);
                     } else {
                         z0_tail(e, z);
+                        tanh_jet_fwd<K, KT, ZN0, ZTN0>(z, y, w);
+                        tanh_jet_bwd<K, KT, ZN0, ZTN0>(z, y, w, At[e], zb);
                     }
-                    tanh_jet_fwd<K, KT>(z, y, w);
-                    tanh_jet_bwd<K, KT>(z, y, w, At[e], zb);
 #pragma unroll
                     for (int j = 0; j < J; ++j) At[e][j] = zb[j];
                     const float bs = row_sum16(zb[0]);
