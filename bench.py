@@ -95,32 +95,48 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kdv7", choices=sorted(WORKLOADS))
-    ap.add_argument("--n", type=int, default=0, help="override points per GPU")
+    ap.add_argument("--points", type=int, default=0, help="override points per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10)
     args = ap.parse_args()
+
+    verbose = os.environ.get("PINN_BENCH_VERBOSE") == "1"
+    if verbose:      # where is a stuck rank?  Python stacks of all threads, every 45 s
+        import faulthandler
+        faulthandler.dump_traceback_later(45, repeat=True, file=sys.stderr)
+
+    def say(msg):
+        if verbose:
+            print("[rank %s] %.2f %s" % (os.environ.get("RANK", "0"), time.time() % 1000, msg), file=sys.stderr, flush=True)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; PINN_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks
+    # (ranks then share devices and the all-reduce goes through the host) - never a measurement
+    backend = os.environ.get("PINN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     group = None
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from pde_amd import scripts
     from pde_amd import _native
 
     w = dict(WORKLOADS[args.workload])
-    if args.n:
-        w["n"] = args.n
+    if args.points:
+        w["n"] = args.points
     n_local = w["n"]
     n_global = n_local * world
     fam = getattr(scripts, w["family"])
@@ -160,9 +176,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    say("model and data ready")
     for _ in range(args.warmup):
         step()
+    say("warm-up launched")
     sync()
+    say("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -172,9 +191,25 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+    say("timed steps done")
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_global * args.steps / elapsed
 
+    # the closure's one collective alone: [grad (P), sum f^2 (nf)] floats, SURVEY 8(e)
+    allreduce_us = None
+    if world > 1:
+        eng0 = model.engine_f
+        msg = torch.zeros(eng0.P + eng0.nf, device=dev)
+        for _ in range(5):
+            dist.all_reduce(msg)
+        sync()
+        t_ar = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(msg)
+        torch.cuda.synchronize()
+        allreduce_us = 1e6 * (time.perf_counter() - t_ar) / 50
+
+    say("all-reduce timed")
     # ---- dominant kernel alone, HIP events on the launch stream (torch's current stream) ----
     eng = model.engine_f
     theta = model.dnn.flat_theta()
@@ -200,6 +235,7 @@ def main():
     except (OSError, ValueError, KeyError):
         traffic = None
 
+    say("kernel timed")
     # ---- full training step (IC/BC terms + Adam) ----
     train_sps = None
     graph_info = None
@@ -224,6 +260,7 @@ def main():
             gs = getattr(model, "graph_stats", None)
             graph_info = {"replays": gs["replays"], "train_steps_per_s": gs["replays"] / gs["seconds"]} if gs else None
 
+    say("training steps timed")
     if rank == 0:
         line = {
             "metric": "collocation residual+grad evals/sec",
@@ -237,11 +274,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (uniform collocation points, xavier-normal weights seed 1234)",
+            "data": "synthetic (uniform collocation points, xavier-normal weights seed 1234)"
+                    + ("" if backend == "nccl" else " - REHEARSAL over %s, not a measurement" % backend),
             "config": {"workload": w["name"], "equation": w["eq"], "layers": w["layers"],
                        "points_per_gpu": n_local, "points_total": n_global,
                        "parallelism": "dp%d over collocation points" % world,
                        "kernel": {1: "valu", 2: "mfma"}[eng.kernel_kind]},
+            "allreduce_us": allreduce_us,
             "train_steps_per_s": train_sps,
             "train_hip_graph": graph_info,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
