@@ -137,6 +137,7 @@ def main():
     w = dict(WORKLOADS[args.workload])
     if args.points:
         w["n"] = args.points
+        w["name"] += " [points per GPU overridden: %d]" % args.points
     n_local = w["n"]
     n_global = n_local * world
     fam = getattr(scripts, w["family"])

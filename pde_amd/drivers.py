@@ -23,6 +23,19 @@ def lhs(n, samples, rng=None):
     return out
 
 
+def lhs_device(n, samples, device, generator=None, dtype=None):
+    """`lhs` generated on `device` as a torch tensor (the 10M-point CH configuration would
+    otherwise spend seconds in numpy permutations and ship 160 MB over PCIe per resampling).  Same
+    construction: one point per stratum and coordinate, uniformly placed, strata paired at random.
+    `set_training_data` accepts the result (after scaling to the domain) as `Xf` without a host copy."""
+    import torch
+    dtype = dtype or torch.float64
+    u = torch.rand((samples, n), device=device, generator=generator, dtype=dtype)
+    cols = [(torch.randperm(samples, device=device, generator=generator).to(dtype) + u[:, j]) / samples
+            for j in range(n)]
+    return torch.stack(cols, dim=1)
+
+
 def load_mat(path, key=None, complex_valued=False):
     """``t, x, Exact_u`` of one of the reference's data files: ``t`` (T,1), ``x`` (X,1), real part of
     ``uu`` as (T,X) (``7kdv/sw-73.py:225-229``); Burgers' ``usol`` is stored (X,T) and transposed

@@ -112,7 +112,8 @@ class PhysicsInformedNN:
     def _shard(self, Xf):
         """Contiguous equal shards of the collocation points over the ranks of the
         process group; remainder goes to the low ranks."""
-        Xf = np.asarray(Xf)
+        if not torch.is_tensor(Xf):
+            Xf = np.asarray(Xf)
         self.n_f_global = Xf.shape[0]
         if self.group is None:
             return Xf
@@ -170,9 +171,15 @@ class PhysicsInformedNN:
             else:
                 self.X_prev = None
         self.tb = self._t(tb)
-        Xf = self._shard(np.asarray(Xf, dtype=np.float64))
-        self.xf = torch.tensor(Xf[:, 0:1]).float().to(self.device).contiguous()
-        self.tf = torch.tensor(Xf[:, 1:2]).float().to(self.device).contiguous()
+        if torch.is_tensor(Xf):
+            # collocation points sampled on the device (drivers.lhs_device): no host round trip
+            Xf = self._shard(Xf.detach())
+            self.xf = Xf[:, 0:1].to(self.device, torch.float32).contiguous()
+            self.tf = Xf[:, 1:2].to(self.device, torch.float32).contiguous()
+        else:
+            Xf = self._shard(np.asarray(Xf, dtype=np.float64))
+            self.xf = torch.tensor(Xf[:, 0:1]).float().to(self.device).contiguous()
+            self.tf = torch.tensor(Xf[:, 1:2]).float().to(self.device).contiguous()
         # the reference reads module globals lb/ub here (:92-93); the sw variants use self.lb
         self.x_lb = torch.full_like(self.tb, float(self.lb[0]))
         self.x_ub = torch.full_like(self.tb, float(self.ub[0]))

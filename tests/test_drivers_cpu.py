@@ -115,3 +115,24 @@ def test_sliding_window_two_output_gnss(tmp_path):
     p = os.path.join(tmp_path, "nls.mat")
     scipy.io.savemat(p, {"t": t, "x": x, "uu": uu})
     assert np.allclose(drivers.load_mat(p, complex_valued=True)[2], uu)
+
+
+def test_lhs_device_and_tensor_collocation_points():
+    """drivers.lhs_device (torch, here on the CPU device) has the Latin-hypercube property, and
+    set_training_data takes a tensor Xf as is (same xf/tf as the numpy route)."""
+    import torch
+    g = torch.Generator().manual_seed(11)
+    H = drivers.lhs_device(2, 50, torch.device("cpu"), generator=g)
+    assert H.shape == (50, 2) and float(H.min()) >= 0.0 and float(H.max()) < 1.0
+    for j in range(2):
+        assert sorted(torch.floor(H[:, j] * 50).long().tolist()) == list(range(50))
+    cls = install(scripts.kdv5_1soliton.PI.PhysicsInformedNN)
+    lb, ub = np.array([-3.0, -0.5]), np.array([3.0, 0.5])
+    Xf = torch.tensor(lb) + torch.tensor(ub - lb) * H
+    x0 = np.linspace(-3, 3, 7)[:, None]
+    tb = np.linspace(-0.5, 0.5, 5)[:, None]
+    a, b = cls([2, 6, 6, 1], lb, ub), cls([2, 6, 6, 1], lb, ub)
+    a.set_training_data(x0, np.exp(-x0 ** 2), tb, Xf)
+    b.set_training_data(x0, np.exp(-x0 ** 2), tb, Xf.numpy())
+    assert a.xf.dtype == torch.float32 and torch.equal(a.xf, b.xf) and torch.equal(a.tf, b.tf)
+    assert a.n_f_global == 50

@@ -119,3 +119,22 @@ def test_graph_replayed_closure_matches_eager_closure():
         assert hasattr(m, "_lbfgs_graph") == graph
     assert res[True][0] == res[False][0]
     assert _rel(res[True][1], res[False][1]) < 1e-3
+
+
+def test_device_sampled_collocation_points_train():
+    """drivers.lhs_device on the GPU -> set_training_data(Xf=tensor) -> a few training steps."""
+    from pde_amd import drivers, scripts
+    dev = torch.device("cuda", 0)
+    lb, ub = np.array([-10.0, -2.0]), np.array([10.0, 2.0])
+    H = drivers.lhs_device(2, 100000, dev, generator=torch.Generator(device=dev).manual_seed(5))
+    assert H.is_cuda and sorted(torch.floor(H[:, 0] * 100000).long().tolist()) == list(range(100000))
+    Xf = torch.tensor(lb, device=dev) + torch.tensor(ub - lb, device=dev) * H
+    m = scripts.kdv5_1soliton.PI.PhysicsInformedNN([2, 50, 50, 50, 50, 1], lb, ub)
+    x0 = np.linspace(-10, 10, 50)[:, None]
+    m.set_training_data(x0, 0.5 / np.cosh(0.5 * x0) ** 2, np.linspace(-2, 2, 50)[:, None], Xf)
+    assert m.xf.shape == (100000, 1) and m.xf.is_cuda
+    l0 = m.backward().item()
+    for p in m.dnn.parameters():
+        p.grad = None
+    m.train(20, LBFGS_max_iter=0)
+    assert m.backward().item() < l0
