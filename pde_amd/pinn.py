@@ -261,10 +261,28 @@ class PhysicsInformedNN:
         loss.backward()
         return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev}
 
+    def check_replicas(self):
+        """Sharded runs keep the weights identical on every rank WITHOUT a broadcast: every rank applies
+        the same optimizer update to the same all-reduced gradient.  This verifies it:
+        the element-wise MIN and MAX over ranks of [sum theta, sum theta^2] must coincide.  Called with
+        the every-100-iterations log line; raises on every rank if the replicas have drifted apart."""
+        if self.group is None:
+            return
+        import torch.distributed as dist
+        th = self.dnn.flat_theta().detach().double()
+        sig = torch.stack([th.sum(), (th * th).sum()])
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("weights differ across ranks (checksums min %s max %s): the replicas no longer "
+                               "follow the same trajectory" % (lo.tolist(), hi.tolist()))
+
     def _log_terms(self, terms):
         """The reference's every-100-iterations log line (the only host syncs of a closure)."""
         if self.iter % 100 != 0:
             return
+        self.check_replicas()
         v = self.variant
         loss, loss0, loss_b, loss_f = terms["loss"], terms["loss0"], terms["loss_b"], terms["loss_f"]
         loss1, loss_prev = terms["loss1"], terms["loss_prev"]

@@ -45,6 +45,22 @@ def _worker(rank, world, port, name, out):
     ref = th.clone()
     dist.broadcast(ref, src=0)
     assert torch.equal(th, ref)
+    m.check_replicas()                       # identical replicas pass the checksum
+    # the L-BFGS phase (pde_amd.lbfgs.LBFGS, CPU stand-in kernels) makes the same decisions on both ranks
+    from lbfgs_cpu_kernels import CpuLBFGSKernels
+    type(m).lbfgs_kernels_factory = staticmethod(lambda n, h: CpuLBFGSKernels(n, h))
+    m.train(0, LBFGS_max_iter=3)
+    assert type(m.optimizer_LBFGS).__module__ == "pde_amd.lbfgs"
+    out["lbfgs_iter_%d" % rank] = m.iter
+    m.check_replicas()
+    if rank == 1:                            # one drifting replica is detected on EVERY rank
+        with torch.no_grad():
+            m.dnn.flat_theta()[3] += 1e-3
+    try:
+        m.check_replicas()
+        out["drift_%d" % rank] = "not detected"
+    except RuntimeError as ex:
+        out["drift_%d" % rank] = "detected" if "differ across ranks" in str(ex) else str(ex)
     dist.destroy_process_group()
 
 
@@ -63,3 +79,5 @@ def test_two_rank_sharding_matches_single_process():
     assert abs(out[0][1] - g["loss_full64"]) <= 1e-5 * g["loss_full64"]
     err = np.linalg.norm(out[0][2].astype(np.float64) - g["grad_full64"]) / np.linalg.norm(g["grad_full64"])
     assert err < 1e-5
+    assert out["drift_0"] == "detected" and out["drift_1"] == "detected"
+    assert out["lbfgs_iter_0"] == out["lbfgs_iter_1"] > 3
