@@ -68,12 +68,18 @@ template <int W> struct WidthCfg {
     // parking in LDS), Zb staged STG tiles at a time, and the weight-gradient tiles go to the
     // workgroup's global slab with hardware float atomics (L2: 123 KB per workgroup) instead of LDS
     // images; the small entries (biases, tails) stay in the compact LDS block.
+    //   Wide layers whose jet set is small (NT*J*4 <= 128 registers: GNSS, Burgers, plain net_u at
+    // width 100) still run EIGHT waves of <= 256 registers: the weight-gradient GEMM then works on one
+    // row of accumulator tiles at a time (STG = 1, flushed by atomics row by row) and one staging tile
+    // and the parked tail rows per wave are all the per-wave LDS there is room for.
     static constexpr bool WIDE = W > 64;
-    static constexpr int WAVES = WIDE ? 4 : PINN_MFMA_BLOCK / 64;
-    static constexpr int BLOCK = 64 * WAVES;
+    static constexpr bool wide8(int J) { return WIDE && NT * J * 4 <= 128; }
+    static constexpr int waves(int J) { return (WIDE && !wide8(J)) ? 4 : PINN_MFMA_BLOCK / 64; }
+    static constexpr int block(int J) { return 64 * waves(J); }
     static constexpr bool WGLOBAL = WIDE;
     static constexpr bool PARK = !WIDE;                        // park registers in LDS around the neuron loops
-    static constexpr int STG = WIDE ? (NT + 2) / 3 : NT;       // Zb tiles staged per pass of the weight-gradient GEMM
+    // Zb tiles staged per pass of the weight-gradient GEMM
+    static constexpr int stg(int J) { return wide8(J) ? 1 : (WIDE ? (NT + 2) / 3 : NT); }
     static constexpr int S = NM + 4;                           // row stride of the main weight image
     // one hidden->hidden layer image in LDS (floats)
     static constexpr int O_BIAS = NM * S;          // [NM]
@@ -125,10 +131,10 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     off += L.gs_size;
     L.wimg = off; off += C::WGLOBAL ? 0 : (d.n_lin - 2) * C::NT * C::NT * 256;
     L.locks = off; off += ((d.n_lin - 2 + 3) / 4) * 4 + 4;
-    L.stage = off; off += C::WAVES * C::STG * STAGE_TILE;
-    L.xt = off; off += C::PARK ? C::WAVES * 128 : 0;
-    L.ztl = off; off += C::WAVES * C::R * J * 16;
-    L.atl = off; off += C::PARK ? C::WAVES * C::R * J * 16 : 0;
+    L.stage = off; off += C::waves(J) * C::stg(J) * STAGE_TILE;
+    L.xt = off; off += C::PARK ? C::waves(J) * 128 : 0;
+    L.ztl = off; off += C::waves(J) * C::R * J * 16;
+    L.atl = off; off += C::PARK ? C::waves(J) * C::R * J * 16 : 0;
     L.total = off;
     return L;
 }
@@ -255,13 +261,14 @@ __device__ __forceinline__ void lds_unlock(int *lk, int lane)
 }
 
 template <int EQ, int W, int MODE>
-__global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArgs a, float *stash)
+__global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<EQ>::KT), 1) void k_mfma(KDesc d, CallArgs a, float *stash)
 {
     typedef WidthCfg<W> C;
     constexpr int NT = C::NT, R = C::R, RR = C::RR, NM = C::NM, S = C::S;
     constexpr bool TAIL = C::TAIL, WGLOBAL = C::WGLOBAL;
-    constexpr int MFMA_BLOCK = C::BLOCK, MFMA_WAVES = C::WAVES, STG = C::STG;
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
+    constexpr int MFMA_BLOCK = C::block(J), MFMA_WAVES = C::waves(J), STG = C::stg(J);
+    constexpr bool GROUPED = C::wide8(J);          // weight-gradient GEMM one row of accumulator tiles at a time
     // the first layer's pre-activation is affine in (x, t): nothing above x-order 1 / t-tangent order 0
     constexpr int ZN0 = K >= 1 ? 1 : 0, ZTN0 = KT >= 1 ? 1 : 0;
     constexpr int TILE = 256;                      // floats of one 16x16 stash image
@@ -326,8 +333,10 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
     const long long wave_g = (long long)blockIdx.x * MFMA_WAVES + wv;
     const long long nwaves = (long long)gridDim.x * MFMA_WAVES;
     const long long ntiles = (a.n + 15) / 16;
-    float *const st = stash + wave_g * (long long)(NH * LAYER_STASH);
-    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(st, 0, NH * LAYER_STASH * 4, 0x00020000);
+    // per wave: the layers' images, then 128 floats where the eight-wave wide shape parks the tile's coordinates
+    const int XT_OFF = NH * LAYER_STASH;
+    float *const st = stash + wave_g * (long long)(NH * LAYER_STASH + 128);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(st, 0, (NH * LAYER_STASH + 128) * 4, 0x00020000);
     float *const stage = lds + L.stage + wv * STG * STAGE_TILE;
     float *const gs = lds + L.gs;
     const float *const io = lds + L.io;
@@ -362,7 +371,10 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
     const float two_scale = uni(2.0f * a.scale);
     float *const xtp = lds + L.xt + wv * 128;
     float *const ztl = lds + L.ztl + wv * (R * ZTL_J * 16);
-    float *const atl = lds + L.atl + wv * (R * ZTL_J * 16);
+    // (eight-wave wide shape: no LDS left for a parking area of its own, but the staging tile is idle
+    // whenever the tail registers are parked and has exactly their size)
+    static_assert(!GROUPED || R * ZTL_J * 16 <= STAGE_TILE, "tail set does not fit the staging tile");
+    float *const atl = GROUPED ? stage : lds + L.atl + wv * (R * ZTL_J * 16);
 
     for (long long tile = wave_g; tile < ntiles; tile += nwaves) {
         PINN_REFRESH();
@@ -374,8 +386,10 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
         // spilled to scratch by the register allocator
         float hx = 2.0f * (xv - d.lbx) / dxr - 1.0f;
         float ht = 2.0f * (tv - d.lbt) / dtr - 1.0f;
-#define PINN_XT_PARK() do { if (C::PARK) { xtp[lane] = hx; xtp[64 + lane] = ht; } } while (0)
-#define PINN_XT_FETCH() do { if (C::PARK) { asm volatile("" ::: "memory"); hx = xtp[lane]; ht = xtp[64 + lane]; } } while (0)
+#define PINN_XT_PARK() do { if (C::PARK) { xtp[lane] = hx; xtp[64 + lane] = ht; } \
+        else if (GROUPED) { sb_store1(srs, lane * 4, XT_OFF, hx); sb_store1(srs, lane * 4, XT_OFF + 64, ht); } } while (0)
+#define PINN_XT_FETCH() do { if (C::PARK) { asm volatile("" ::: "memory"); hx = xtp[lane]; ht = xtp[64 + lane]; } \
+        else if (GROUPED) { asm volatile("" ::: "memory"); hx = sb_load1(srs, lane * 4, XT_OFF); ht = sb_load1(srs, lane * 4, XT_OFF + 64); } } while (0)
         if (MODE != MODE_FWD) PINN_XT_PARK();
 
         // The one register-resident set: activations on the way up, adjoints on the way down.
@@ -383,9 +397,9 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
         float At[RR][J];       // tail neurons (same value in all four lane quads)
         // The reverse sweep's per-neuron loops need every register they can get: the tail set is parked
         // in LDS around them.
-#define PINN_AT_PARK() do { if (TAIL && C::PARK) { if (q == 0) { _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
+#define PINN_AT_PARK() do { if (TAIL && (C::PARK || GROUPED)) { if (q == 0) { _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
             atl[(e * ZTL_J + j) * 16 + p] = At[e][j]; } } } while (0)
-#define PINN_AT_FETCH() do { if (TAIL && C::PARK) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
+#define PINN_AT_FETCH() do { if (TAIL && (C::PARK || GROUPED)) { asm volatile("" ::: "memory"); _Pragma("unroll") for (int e = 0; e < R; ++e) _Pragma("unroll") for (int j = 0; j < J; ++j) \
             At[e][j] = atl[(e * ZTL_J + j) * 16 + p]; } } while (0)
 
         // first-layer pre-activation jets (also recomputed in the reverse sweep: they are affine in (x,t),
@@ -560,7 +574,10 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                         if (j == 0) s += img[C::O_BT + e];
 #pragma unroll
                         for (int e2 = 0; e2 < R; ++e2) s = fmaf(img[C::O_WTT + e * 4 + e2], At[e2][j], s);
-                        zt[e][j] = s;
+                        // (eight-wave wide shape: the tail pre-activations wait in the idle staging tile, not
+                        // in registers, until the tiled neurons are done)
+                        if (GROUPED) { if (q == 0) stage[(e * J + j) * 16 + p] = s; }
+                        else zt[e][j] = s;
                         PINN_SB();
                     }
                 }
@@ -601,6 +618,11 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
                     float y[J], w[K + 1];
+                    if (GROUPED) {
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int j = 0; j < J; ++j) zt[e][j] = stage[(e * J + j) * 16 + p];
+                    }
                     tanh_jet_fwd<K, KT>(zt[e], y, w);
                     if (topl) {
                         out_acc_tail(e, y);
@@ -788,6 +810,67 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
 
             // Phase A: Wb[o][i] += sum_{p,k} Zb_k[o][p] * Y_k[i][p]   (reduction over points)
             {
+                // The tail rows of Zb are parked in LDS as [component][point]: their weight gradient against
+                // the tiled y_{l-1} is formed in the tanh layer below, where y_{l-1} is recomputed anyway.
+                if (TAIL) {
+                    if (q == 0) {
+#pragma unroll
+                        for (int e = 0; e < R; ++e)
+#pragma unroll
+                            for (int j = 0; j < J; ++j) ztl[(e * ZTL_J + j) * 16 + p] = At[e][j];
+                    }
+                }
+                if constexpr (GROUPED) {
+                    // One row of accumulator tiles (output neurons 16To..16To+15) at a time: NT tiles of
+                    // accumulators instead of NT*NT, at the price of re-reading y from the stash NT times.
+                    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + 2) * 4, 0x00020000);
+                    const int gvoff = (4 * q * W + p) * 4;
+                    const int gsoff = d.woff[l] * 4;
+#pragma unroll
+                    for (int To = 0; To < NT; ++To) {
+                        f32x4 wrow[NT];
+#pragma unroll
+                        for (int Ti = 0; Ti < NT; ++Ti) wrow[Ti] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            float bopg[NT][4];
+                            // (scalar base re-derived per use: hoisted, the NT*J*4 stash offsets of a layer
+                            // would stay live in SGPRs over all NT passes)
+                            int ypo = yprev + j * TILE;
+                            asm volatile("" : "+s"(ypo));
+#pragma unroll
+                            for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) bopg[Ti][s] = sb_load1(srs, vyn, ypo + Ti * J * TILE + s * 16);
+                            *(f32x4 *)&stage[p * STAGE_ROW + 4 * q] = A[To][j];
+                            PINN_LDS_FENCE();
+                            float aopg[4];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) aopg[s] = stage[(4 * q + s) * STAGE_ROW + p];
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) pin(aopg[s]);
+                            PINN_SB();
+#pragma unroll
+                            for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                                for (int s = 0; s < 4; ++s) wrow[Ti] = mfma4(aopg[s], bopg[Ti][s], wrow[Ti]);
+                            PINN_JB();
+                        }
+                        if (!PINN_ABL_WACC || rt_false) {
+                            // scalar offset of this row of tiles, re-derived here: formed once per layer the 144
+                            // per-tile offsets would all be live (and spilled) across the whole phase
+                            int gso = gsoff + 16 * To * W * 4;
+                            asm volatile("" : "+s"(gso));
+#pragma unroll
+                            for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (TAIL || (16 * To + 4 * q + r < W && 16 * Ti + p < W))
+                                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wrow[Ti][r], grs, gvoff,
+                                                                                        gso + (r * W + 16 * Ti) * 4, 0);
+                        }
+                    }
+                } else {
                 f32x4 wacc[NT][NT];
 #pragma unroll
                 for (int To = 0; To < NT; ++To)
@@ -799,16 +882,6 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                 //  A operand: Zb through the staging image [point][neuron] -> lane (m = p, kk = q) reads
                 //             Zb[16To + m][point 4kk + s]
                 float bop[2][NT][4];
-                // The tail rows of Zb are parked in LDS as [component][point]: their weight gradient against
-                // the tiled y_{l-1} is formed in the tanh layer below, where y_{l-1} is recomputed anyway.
-                if (TAIL) {
-                    if (q == 0) {
-#pragma unroll
-                        for (int e = 0; e < R; ++e)
-#pragma unroll
-                            for (int j = 0; j < J; ++j) ztl[(e * ZTL_J + j) * 16 + p] = At[e][j];
-                    }
-                }
 #pragma unroll
                 for (int Ti = 0; Ti < NT; ++Ti)
 #pragma unroll
@@ -883,6 +956,7 @@ __global__ __launch_bounds__(WidthCfg<W>::BLOCK, 1) void k_mfma(KDesc d, CallArg
                             *dst = *dst + wacc[To][Ti];
                         }
                     lds_unlock(lk, lane);
+                }
                 }
                 PINN_SB();
                 if (TAIL) {
@@ -1199,10 +1273,10 @@ struct MfmaPlan {
 template <int W> size_t mfma_lds_bytes(const KDesc &kd, int J) { return (size_t)mfma_layout<W>(kd, J).total * sizeof(float); }
 
 // waves per workgroup / whether the kernel accumulates straight into the (pre-zeroed) slab
-inline int mfma_waves(const KDesc &kd)
+inline int mfma_waves(const KDesc &kd, int J)
 {
     switch (kd.widths[1]) {
-#define X(w) case w: return WidthCfg<w>::WAVES;
+#define X(w) case w: return WidthCfg<w>::waves(J);
         PINN_MFMA_WIDTHS(X)
 #undef X
     default: return MFMA_MAX_WAVES;
@@ -1240,7 +1314,7 @@ template <int W> size_t mfma_stash_per_wave(const KDesc &kd, int J)
     typedef WidthCfg<W> C;
     const size_t ZY = (size_t)C::NT * J * 256;
     const size_t TS = (size_t)((C::RR * J * 16 + 63) / 64) * 64;
-    return (size_t)(kd.n_lin - 1) * (2 * ZY + 2 * TS);
+    return (size_t)(kd.n_lin - 1) * (2 * ZY + 2 * TS) + 128;
 }
 
 inline size_t mfma_stash_floats(const KDesc &kd, int J)
@@ -1282,7 +1356,7 @@ int launch_mfma_t(MfmaPlan &pl, const KDesc &kd, const CallArgs &a, int grid, hi
             return -3;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WidthCfg<W>::BLOCK), ldsb, st, kd, a, pl.stash);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<EQ>::KT)), ldsb, st, kd, a, pl.stash);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

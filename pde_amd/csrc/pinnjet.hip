@@ -153,7 +153,7 @@ int run_mfma(MfmaPlan &pl, const KDesc &kd, int eq, int mode, CallArgs a, float 
     if (eq_orders(eq, kd.nout, &K, &KT, &nf)) return PINN_ERR_INVALID_DESC;
     const int J = K + 1 + KT;
     const long long ntiles = (a.n + 15) / 16;
-    const int waves = mfma_waves(kd);
+    const int waves = mfma_waves(kd, J);
     const long long need_blocks = (ntiles + waves - 1) / waves;
     const int grid = (int)(need_blocks < pl.grid ? need_blocks : pl.grid);
     int rc;
