@@ -826,48 +826,62 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + 2) * 4, 0x00020000);
                     const int gvoff = (4 * q * W + p) * 4;
                     const int gsoff = d.woff[l] * 4;
+#ifndef PINN_GR
+#define PINN_GR 3
+#endif
+                    constexpr int GR = (NT % PINN_GR == 0) ? PINN_GR : (NT % 2 == 0 ? 2 : 1);     // rows of tiles per pass
 #pragma unroll
-                    for (int To = 0; To < NT; ++To) {
-                        f32x4 wrow[NT];
+                    for (int Tg = 0; Tg < NT; Tg += GR) {
+                        f32x4 wrow[GR][NT];
 #pragma unroll
-                        for (int Ti = 0; Ti < NT; ++Ti) wrow[Ti] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                        for (int t = 0; t < GR; ++t)
+#pragma unroll
+                            for (int Ti = 0; Ti < NT; ++Ti) wrow[t][Ti] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                         for (int j = 0; j < J; ++j) {
                             float bopg[NT][4];
                             // (scalar base re-derived per use: hoisted, the NT*J*4 stash offsets of a layer
-                            // would stay live in SGPRs over all NT passes)
+                            // would stay live in SGPRs over all passes)
                             int ypo = yprev + j * TILE;
                             asm volatile("" : "+s"(ypo));
 #pragma unroll
                             for (int Ti = 0; Ti < NT; ++Ti)
 #pragma unroll
                                 for (int s = 0; s < 4; ++s) bopg[Ti][s] = sb_load1(srs, vyn, ypo + Ti * J * TILE + s * 16);
-                            *(f32x4 *)&stage[p * STAGE_ROW + 4 * q] = A[To][j];
-                            PINN_LDS_FENCE();
-                            float aopg[4];
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) aopg[s] = stage[(4 * q + s) * STAGE_ROW + p];
+                            for (int t = 0; t < GR; ++t) {
+                                // the one staging tile is re-used row after row (LDS operations of a wave are in order)
+                                *(f32x4 *)&stage[p * STAGE_ROW + 4 * q] = A[Tg + t][j];
+                                PINN_LDS_FENCE();
+                                float aopg[4];
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) pin(aopg[s]);
-                            PINN_SB();
+                                for (int s = 0; s < 4; ++s) aopg[s] = stage[(4 * q + s) * STAGE_ROW + p];
 #pragma unroll
-                            for (int Ti = 0; Ti < NT; ++Ti)
+                                for (int s = 0; s < 4; ++s) pin(aopg[s]);
+                                PINN_SB();
 #pragma unroll
-                                for (int s = 0; s < 4; ++s) wrow[Ti] = mfma4(aopg[s], bopg[Ti][s], wrow[Ti]);
+                                for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                                    for (int s = 0; s < 4; ++s) wrow[t][Ti] = mfma4(aopg[s], bopg[Ti][s], wrow[t][Ti]);
+                                PINN_SB();
+                            }
                             PINN_JB();
                         }
                         if (!PINN_ABL_WACC || rt_false) {
-                            // scalar offset of this row of tiles, re-derived here: formed once per layer the 144
-                            // per-tile offsets would all be live (and spilled) across the whole phase
-                            int gso = gsoff + 16 * To * W * 4;
-                            asm volatile("" : "+s"(gso));
 #pragma unroll
-                            for (int Ti = 0; Ti < NT; ++Ti)
+                            for (int t = 0; t < GR; ++t) {
+                                // scalar offset of this row of tiles, re-derived here: formed once per layer the
+                                // per-tile offsets would all be live (and spilled) across the whole phase
+                                int gso = gsoff + 16 * (Tg + t) * W * 4;
+                                asm volatile("" : "+s"(gso));
 #pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    if (TAIL || (16 * To + 4 * q + r < W && 16 * Ti + p < W))
-                                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wrow[Ti][r], grs, gvoff,
-                                                                                        gso + (r * W + 16 * Ti) * 4, 0);
+                                for (int Ti = 0; Ti < NT; ++Ti)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        if (TAIL || (16 * (Tg + t) + 4 * q + r < W && 16 * Ti + p < W))
+                                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wrow[t][Ti][r], grs, gvoff,
+                                                                                            gso + (r * W + 16 * Ti) * 4, 0);
+                            }
                         }
                     }
                 } else {
