@@ -269,6 +269,11 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
     constexpr int MFMA_BLOCK = C::block(J), MFMA_WAVES = C::waves(J), STG = C::stg(J);
     constexpr bool GROUPED = C::wide8(J);          // weight-gradient GEMM one row of accumulator tiles at a time
+#ifndef PINN_ZT_LDS_ALL
+#define PINN_ZT_LDS_ALL 1
+#endif
+    // forward tail pre-activations wait in the (idle) staging area instead of in registers
+    constexpr bool ZT_LDS = GROUPED || (PINN_ZT_LDS_ALL && TAIL && R * J * 16 <= STG * STAGE_TILE);
     // the first layer's pre-activation is affine in (x, t): nothing above x-order 1 / t-tangent order 0
     constexpr int ZN0 = K >= 1 ? 1 : 0, ZTN0 = KT >= 1 ? 1 : 0;
     constexpr int TILE = 256;                      // floats of one 16x16 stash image
@@ -367,7 +372,9 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     // wave-uniform: keep them in SGPRs
     auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
     const float dxr = uni(d.ubx - d.lbx), dtr = uni(d.ubt - d.lbt);
-    const float sx = uni(2.0f / dxr), stt = uni(2.0f / dtr);
+    // the chain-rule factors come in as kernel arguments (SGPRs): computed here, the compiler proves them
+    // uniform, keeps the quotients in VGPRs, spills them and reloads them at every use
+    const float sx = d.sx, stt = d.st;
     const float two_scale = uni(2.0f * a.scale);
     float *const xtp = lds + L.xt + wv * 128;
     float *const ztl = lds + L.ztl + wv * (R * ZTL_J * 16);
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                         for (int e2 = 0; e2 < R; ++e2) s = fmaf(img[C::O_WTT + e * 4 + e2], At[e2][j], s);
                         // (eight-wave wide shape: the tail pre-activations wait in the idle staging tile, not
                         // in registers, until the tiled neurons are done)
-                        if (GROUPED) { if (q == 0) stage[(e * J + j) * 16 + p] = s; }
+                        if (ZT_LDS) { if (q == 0) stage[(e * J + j) * 16 + p] = s; }
                         else zt[e][j] = s;
                         PINN_SB();
                     }
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
 #pragma unroll
                 for (int e = 0; e < R; ++e) {
                     float y[J], w[K + 1];
-                    if (GROUPED) {
+                    if (ZT_LDS) {
                         asm volatile("" ::: "memory");
 #pragma unroll
                         for (int j = 0; j < J; ++j) zt[e][j] = stage[(e * J + j) * 16 + p];
@@ -1189,7 +1196,10 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         {
             float *gw0 = p_w0;
 #pragma unroll
-            for (int T = 0; T < NT; ++T)
+            for (int T = 0; T < NT; ++T) {
+                // (coordinates re-read from their LDS parking slot per tile of neurons: kept in registers over
+                // the whole phase they are spilled to scratch and reloaded neuron by neuron)
+                if (C::PARK) { asm volatile("" ::: "memory"); hx = xtp[lane]; ht = xtp[64 + lane]; }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float g0 = A[T][0][r];
@@ -1204,6 +1214,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                         PINN_ADD_S(&gw0[2 * n + 1], gt);
                     }
                 }
+            }
             if (TAIL) {
 #pragma unroll
                 for (int e = 0; e < R; ++e) {

@@ -17,6 +17,7 @@ struct KDesc {
     int nout;                     // widths[n_lin]
     float lbx, lbt, ubx, ubt;     // Scale bounds
     float coef[8];                // residual coefficients
+    float sx, st;                 // 2/(ubx-lbx), 2/(ubt-lbt): d(scaled coordinate)/d(coordinate)
 };
 
 enum { MODE_FWD = 0, MODE_VJP = 1, MODE_LOSS = 2 };

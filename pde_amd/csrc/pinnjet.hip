@@ -231,6 +231,8 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     kd.nout = nout;
     kd.lbx = desc->lb[0]; kd.lbt = desc->lb[1];
     kd.ubx = desc->ub[0]; kd.ubt = desc->ub[1];
+    kd.sx = 2.0f / (kd.ubx - kd.lbx);
+    kd.st = 2.0f / (kd.ubt - kd.lbt);
     for (int i = 0; i < 8; ++i) kd.coef[i] = desc->coef[i];
 
     if (hipGetDevice(&h->device) != hipSuccess) { (void)hipGetLastError(); delete h; return PINN_ERR_HIP; }

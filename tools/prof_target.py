@@ -18,6 +18,7 @@ ap.add_argument("--n", type=int, default=0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--kernel", type=int, default=0)
 ap.add_argument("--lib", default="", help="alternative libpinnjet.so (development builds)")
+ap.add_argument("--check", action="store_true", help="compare loss/gradient with the VALU kernels of the same library")
 args = ap.parse_args()
 if args.lib:
     import pde_amd._native as _nat
@@ -40,6 +41,16 @@ th = torch.tensor(theta, device=dev)
 x = torch.tensor(X[:, 0].copy(), device=dev)
 t = torch.tensor(X[:, 1].copy(), device=dev)
 buf = torch.zeros(eng.P + eng.nf, device=dev)
+if args.check:
+    nc = min(n, 20000)
+    ref = NativeEngine(equations.get(w["eq"]), w["layers"], lb, ub, dev, kernel=1)
+    b0, b1 = torch.zeros_like(buf), torch.zeros_like(buf)
+    eng.loss_grad(th, x[:nc], t[:nc], 1.0 / nc, b0[eng.P:], b0[:eng.P])
+    ref.loss_grad(th, x[:nc], t[:nc], 1.0 / nc, b1[eng.P:], b1[:eng.P])
+    torch.cuda.synchronize()
+    gerr = float((b0[:eng.P] - b1[:eng.P]).norm() / b1[:eng.P].norm())
+    lerr = float(((b0[eng.P:] - b1[eng.P:]).abs() / b1[eng.P:].abs()).max())
+    print("check vs valu kernels (n=%d): loss rel %.2e grad rel %.2e %s" % (nc, lerr, gerr, "OK" if gerr < 1e-4 and lerr < 1e-4 else "MISMATCH"))
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(args.iters):
     ev0.record()
