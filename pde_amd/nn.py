@@ -7,6 +7,10 @@ shipped .pth checkpoints load and saved ones load back into the reference) but
 
   * every Linear weight/bias is a view into ONE flat float32 buffer `theta`
     in state-dict order, which is what the kernels read;
+  * autograd sees ONE leaf (`grad_leaf()`, the same storage): the native ops hand
+    it one flat gradient per backward pass, and a post-accumulate hook gives each
+    parameter its slice as `.grad` (views, no copies) — instead of ten small
+    accumulation kernels per op and pass;
   * calling the module runs the fused Scale+MLP HIP kernel through a
     torch.autograd.Function instead of a chain of addmm/tanh ATen ops.
 """
@@ -54,21 +58,13 @@ def xavier(m):
             torch.nn.init.zeros_(m.bias)
 
 
-def _split_flat(flat, params):
-    out, off = [], 0
-    for p in params:
-        n = p.numel()
-        out.append(flat[off:off + n].view(p.shape))
-        off += n
-    return out
-
-
 class _NetUFn(torch.autograd.Function):
     """u = dnn([x,t]) with a theta-gradient.  No gradient flows to the inputs: the
-    reference differentiates w.r.t. x,t only inside net_f, which has its own op."""
+    reference differentiates w.r.t. x,t only inside net_f, which has its own op.
+    `leaf` is NetU.grad_leaf(): the one autograd leaf standing for all parameters."""
 
     @staticmethod
-    def forward(ctx, net, X, *params):
+    def forward(ctx, net, X, leaf):
         theta = net.flat_theta()
         ctx.net = net
         ctx.X = X
@@ -80,14 +76,14 @@ class _NetUFn(torch.autograd.Function):
         theta = net.flat_theta()
         g = torch.zeros_like(theta)
         net.engine.forward_vjp(theta, ctx.X, None, gout, g)
-        return (None, None) + tuple(_split_flat(g, net.param_list))
+        return None, None, g
 
 
 class _ResidualFn(torch.autograd.Function):
     """f = net_f(x, t) as an (N, nf) tensor whose backward reaches the weights."""
 
     @staticmethod
-    def forward(ctx, net, engine, x, t, *params):
+    def forward(ctx, net, engine, x, t, leaf):
         theta = net.flat_theta()
         ctx.net, ctx.engine, ctx.x, ctx.t = net, engine, x, t
         return engine.residual_fwd(theta, x, t)
@@ -98,7 +94,7 @@ class _ResidualFn(torch.autograd.Function):
         theta = net.flat_theta()
         g = torch.zeros_like(theta)
         ctx.engine.residual_vjp(theta, ctx.x, ctx.t, gout, g)
-        return (None, None, None, None) + tuple(_split_flat(g, net.param_list))
+        return None, None, None, None, g
 
 
 class _ResidualLossFn(torch.autograd.Function):
@@ -108,7 +104,7 @@ class _ResidualLossFn(torch.autograd.Function):
     all-reduced once: [grad (P floats), sum f_c^2 (nf floats)]."""
 
     @staticmethod
-    def forward(ctx, net, engine, x, t, n_global, group, *params):
+    def forward(ctx, net, engine, x, t, n_global, group, leaf):
         theta = net.flat_theta()
         buf = torch.zeros(engine.P + engine.nf, dtype=torch.float32, device=theta.device)
         if x.numel() > 0:
@@ -121,8 +117,7 @@ class _ResidualLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        g = ctx.grad_flat * gout
-        return (None, None, None, None, None, None) + tuple(_split_flat(g, ctx.net.param_list))
+        return None, None, None, None, None, None, ctx.grad_flat * gout
 
 
 class NetU(torch.nn.Sequential):
@@ -151,6 +146,45 @@ class NetU(torch.nn.Sequential):
             off += n
         self._theta = flat
         self.param_list = params
+        # the autograd leaf of the native ops: same storage as the parameters
+        self._leaf = flat.detach().requires_grad_(True)
+        self._leaf.register_post_accumulate_grad_hook(self._distribute_grad)
+
+    def grad_leaf(self):
+        self.flat_theta()
+        return self._leaf
+
+    def _distribute_grad(self, leaf):
+        """Runs once per backward pass, after autograd has summed the flat gradients of all native ops:
+        every parameter gets its slice.  `.grad` is None (after zero_grad(set_to_none=True)): the
+        slices become the `.grad` tensors, no kernel at all.  `.grad` are consecutive views of one
+        buffer (pde_amd.lbfgs.LBFGS keeps them so): one flat add.  Otherwise: one add per parameter,
+        the usual accumulating semantics."""
+        g = leaf.grad
+        leaf.grad = None
+        params = self.param_list
+        first = params[0].grad
+        if first is not None:
+            base, off, flat_ok = first.data_ptr(), 0, first.dtype == torch.float32
+            for p in params:
+                gp = p.grad
+                if gp is None or gp.data_ptr() != base + 4 * off or not gp.is_contiguous():
+                    flat_ok = False
+                    break
+                off += p.numel()
+            if flat_ok:
+                first.as_strided((off,), (1,)).add_(g)
+                return
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.requires_grad:
+                v = g[off:off + n].view(p.shape)
+                if p.grad is None:
+                    p.grad = v
+                else:
+                    p.grad.add_(v)
+            off += n
 
     def flat_theta(self):
         """The contiguous float32 parameter vector the kernels read.  Parameters are
@@ -170,4 +204,4 @@ class NetU(torch.nn.Sequential):
             raise ValueError("dnn expects an (N,2) tensor of [x,t] rows")
         if X.shape[0] == 0:
             return torch.zeros((0, self.layer_sizes[-1]), device=self._device)
-        return _NetUFn.apply(self, X.detach().contiguous(), *self.param_list)
+        return _NetUFn.apply(self, X.detach().contiguous(), self.grad_leaf())

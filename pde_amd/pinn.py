@@ -207,7 +207,7 @@ class PhysicsInformedNN:
         w.r.t. the weights.  Reference: nested autograd chain, :122-132."""
         x = x.detach().to(self.device, torch.float32)
         t = t.detach().to(self.device, torch.float32)
-        f = _ResidualFn.apply(self.dnn, self.engine_f, x, t, *self.dnn.param_list)
+        f = _ResidualFn.apply(self.dnn, self.engine_f, x, t, self.dnn.grad_leaf())
         if self.equation.nf == 2:
             return f[:, 0:1], f[:, 1:2]
         return f
@@ -216,7 +216,7 @@ class PhysicsInformedNN:
         """mean(square(f)) (summed over components) over ALL ranks' collocation points,
         fused with its weight gradient; one all-reduce when sharded."""
         return _ResidualLossFn.apply(self.dnn, self.engine_f, self.xf, self.tf, self.n_f_global, self.group,
-                                     *self.dnn.param_list)
+                                     self.dnn.grad_leaf())
 
     def _mse(self, pred, *targets):
         s = 0

@@ -65,8 +65,13 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--n", type=int, default=20000)
     ap.add_argument("--cases", default="burgers,kdv5,kdv7,gnss")
+    ap.add_argument("--only", default="", help="run just this variant: torch | device | device+graph (profiling)")
     a = ap.parse_args()
     for case in a.cases.split(","):
+        if a.only:
+            r1 = run(case, "torch" if a.only == "torch" else "device", a.n, a.iters, graph=a.only == "device+graph")
+            print(json.dumps({"case": case, "n_f": a.n, a.only: r1}), flush=True)
+            continue
         r = {impl: run(case, impl, a.n, a.iters) for impl in ("torch", "device")}
         r["device+graph"] = run(case, "device", a.n, a.iters, graph=True)
         print(json.dumps({"case": case, "n_f": a.n, **r,
