@@ -59,6 +59,16 @@ int ensure(float **buf, size_t *have, size_t need)
 
 // Sum the per-workgroup partial slabs in a fixed order (deterministic for a
 // given grid) and accumulate into the caller's gradient / loss buffers.
+// zero the per-workgroup slabs of the wide shapes (they are accumulated into with atomics).  A kernel, not
+// hipMemsetAsync: as a memset NODE of a captured HIP graph the clear was not reliably ordered before the
+// kernel on replays (the main blocks of the hidden-layer gradients came back accumulated / non-finite from
+// the second replay on); a kernel node in the same stream is.
+__global__ __launch_bounds__(256) void k_zero_floats(float *p, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.0f;
+}
+
 __global__ __launch_bounds__(256) void k_reduce_slabs(const float *slab, int nblk, int P, float *grad_accum,
                                                       float *loss_accum, int nf)
 {
@@ -166,7 +176,11 @@ int run_mfma(MfmaPlan &pl, const KDesc &kd, int eq, int mode, CallArgs a, float 
         if (rc) return rc;
         a.slab = pl.slab;
         // wide layers accumulate into their slab with atomics: it has to start at zero
-        if (mfma_wglobal(kd) && hipMemsetAsync(pl.slab, 0, slab_bytes, st) != hipSuccess) return PINN_ERR_HIP;
+        if (mfma_wglobal(kd)) {
+            const long long nfl = (long long)(slab_bytes / sizeof(float));
+            const int zb = (int)((nfl + 256 * 8 - 1) / (256 * 8) < 2048 ? (nfl + 256 * 8 - 1) / (256 * 8) : 2048);
+            hipLaunchKernelGGL(k_zero_floats, dim3(zb > 0 ? zb : 1), dim3(256), 0, st, pl.slab, nfl);
+        }
     }
     switch (mode) {
     case MODE_FWD:  rc = launch_mfma_eq<MODE_FWD>(pl, eq, kd, a, grid, st); break;

@@ -146,17 +146,17 @@ class NetU(torch.nn.Sequential):
             off += n
         self._theta = flat
         self.param_list = params
-        # the autograd leaf of the native ops: same storage as the parameters
-        self._leaf = flat.detach().requires_grad_(True)
-        self._leaf.register_post_accumulate_grad_hook(self._distribute_grad)
 
     def grad_leaf(self):
-        self.flat_theta()
-        return self._leaf
+        """The autograd leaf a native op takes as its parameter input: a fresh alias of the flat buffer
+        per call (no kernel), so that its gradient accumulation runs on the stream the op runs on —
+        a cached leaf keeps the stream of its first use, which breaks HIP-graph capture on another one."""
+        leaf = self.flat_theta().detach().requires_grad_(True)
+        leaf.register_post_accumulate_grad_hook(self._distribute_grad)
+        return leaf
 
     def _distribute_grad(self, leaf):
-        """Runs once per backward pass, after autograd has summed the flat gradients of all native ops:
-        every parameter gets its slice.  `.grad` is None (after zero_grad(set_to_none=True)): the
+        """Runs once per native op and backward pass: every parameter gets its slice of the op's flat gradient.  `.grad` is None (after zero_grad(set_to_none=True)): the
         slices become the `.grad` tensors, no kernel at all.  `.grad` are consecutive views of one
         buffer (pde_amd.lbfgs.LBFGS keeps them so): one flat add.  Otherwise: one add per parameter,
         the usual accumulating semantics."""

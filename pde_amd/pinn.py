@@ -184,6 +184,10 @@ class PhysicsInformedNN:
         self.x_lb = torch.full_like(self.tb, float(self.lb[0]))
         self.x_ub = torch.full_like(self.tb, float(self.ub[0]))
         self.t0 = torch.full_like(self.x0, t0)
+        # IC, lower-boundary and upper-boundary points as ONE (n0 + 2 nb, 2) batch, built once
+        self._X_data = torch.cat([torch.cat([self.x0, self.t0], dim=1),
+                                  torch.cat([self.x_lb, self.tb], dim=1),
+                                  torch.cat([self.x_ub, self.tb], dim=1)], dim=0).contiguous()
 
     def set_nu(self, nu):
         """Burgers viscosity: a float32 tensor in the reference (:96); a new value needs
@@ -232,9 +236,7 @@ class PhysicsInformedNN:
         # the three small data-term batches (IC, lower and upper boundary) go through net_u as ONE
         # batch: one forward and one vjp launch instead of three each (same values per point)
         n0, nb = self.x0.shape[0], self.x_lb.shape[0]
-        out_all = self.dnn(torch.cat([torch.cat([self.x0, self.t0], dim=1),
-                                      torch.cat([self.x_lb, self.tb], dim=1),
-                                      torch.cat([self.x_ub, self.tb], dim=1)], dim=0))
+        out_all = self.dnn(self._X_data)
         out0, out_lb, out_ub = out_all[:n0], out_all[n0:n0 + nb], out_all[n0 + nb:]
         loss0 = self._mse(out0, self.u0, self.v0) if two else self._mse(out0, self.u0)
         if v.bc == "dirichlet":

@@ -138,3 +138,35 @@ def test_device_sampled_collocation_points_train():
         p.grad = None
     m.train(20, LBFGS_max_iter=0)
     assert m.backward().item() < l0
+
+
+@pytest.mark.parametrize("width", [50, 100])
+def test_graph_replay_reproduces_eager_gradient(width):
+    """The captured L-BFGS closure replayed several times gives the eager closure's loss and gradient
+    every time.  Width 100 accumulates its weight-gradient tiles into a per-workgroup slab with
+    atomics; the slab is cleared by a kernel (as a memset node of the graph the clear was not ordered
+    before the kernel on later replays and the gradient came back accumulated / non-finite)."""
+    from pde_amd import scripts
+    from pde_amd.lbfgs import LBFGS
+    torch.manual_seed(4)
+    lb, ub = np.array([-1.0, 0.0]), np.array([1.0, 0.99])
+    m = scripts.burgers.PI.PhysicsInformedNN([2, width, width, width, 1], lb, ub)
+    rng = np.random.default_rng(1)
+    x0 = rng.uniform(lb[0], ub[0], (50, 1)); tb = rng.uniform(lb[1], ub[1], (50, 1))
+    m.set_training_data(x0, -np.sin(np.pi * x0), tb, lb + (ub - lb) * rng.random((5000, 2)), 0.01 / np.pi)
+    opt = LBFGS(list(m.dnn.parameters()), flat_params=m.dnn.flat_theta(), history_size=5, line_search_fn="strong_wolfe")
+    m.optimizer_LBFGS = opt
+    opt.zero_grad()
+    loss_e = float(m._loss_terms()["loss"].detach())
+    torch.cuda.synchronize()
+    g_e = opt.flat_grad().clone()
+    closure = m._graph_closure()
+    assert closure is not None
+    m.iter = 1
+    for _ in range(4):
+        loss = closure()
+        torch.cuda.synchronize()
+        g = opt.flat_grad()
+        assert torch.isfinite(g).all()
+        assert abs(float(loss.detach()) - loss_e) <= 1e-6 * abs(loss_e)
+        assert float((g - g_e).norm() / g_e.norm()) < 1e-5
