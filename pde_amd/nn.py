@@ -79,6 +79,40 @@ class _NetUFn(torch.autograd.Function):
         return None, None, g
 
 
+class _DataLossFn(torch.autograd.Function):
+    """loss_0 and loss_b of the reference's backward() (:99-105; Dirichlet form:
+    Burgers/Burgers_equation(PINN).py:109) as ONE op over the batch X = [IC points | lower-boundary
+    points | upper-boundary points]: one net_u forward, the two mean-square sums, and in backward one
+    net_u vjp with the cotangent 2 r / n.  Same values as the chain of torch ops it replaces (the sums
+    run over all columns at once), a dozen fewer kernels and autograd nodes per closure."""
+
+    @staticmethod
+    def forward(ctx, net, X, tgt0, n0, nb, dirichlet, leaf):
+        theta = net.flat_theta()
+        out = net.engine.forward(theta, X, None)
+        r0 = out[:n0] - tgt0
+        rb = out[n0:] if dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
+        ctx.net, ctx.X, ctx.r0, ctx.rb = net, X, r0, rb
+        ctx.n0, ctx.nb, ctx.dirichlet = n0, nb, dirichlet
+        return (r0 * r0).sum() / n0, (rb * rb).sum() / nb
+
+    @staticmethod
+    def backward(ctx, g0, gb):
+        net, n0, nb = ctx.net, ctx.n0, ctx.nb
+        theta = net.flat_theta()
+        gbar = torch.empty((n0 + 2 * nb, ctx.r0.shape[1]), dtype=torch.float32, device=theta.device)
+        gbar[:n0] = ctx.r0 * (g0 * (2.0 / n0))
+        tb = ctx.rb * (gb * (2.0 / nb))
+        if ctx.dirichlet:
+            gbar[n0:] = tb
+        else:
+            gbar[n0:n0 + nb] = tb
+            gbar[n0 + nb:] = -tb
+        g = torch.zeros_like(theta)
+        net.engine.forward_vjp(theta, ctx.X, None, gbar, g)
+        return None, None, None, None, None, None, g
+
+
 class _ResidualFn(torch.autograd.Function):
     """f = net_f(x, t) as an (N, nf) tensor whose backward reaches the weights."""
 

@@ -23,7 +23,7 @@ import torch
 
 from . import equations
 from ._native import KERNEL_AUTO, NativeEngine
-from .nn import NetU, _ResidualFn, _ResidualLossFn
+from .nn import NetU, _DataLossFn, _ResidualFn, _ResidualLossFn
 
 
 class FileWriter:
@@ -188,6 +188,7 @@ class PhysicsInformedNN:
         self._X_data = torch.cat([torch.cat([self.x0, self.t0], dim=1),
                                   torch.cat([self.x_lb, self.tb], dim=1),
                                   torch.cat([self.x_ub, self.tb], dim=1)], dim=0).contiguous()
+        self._tgt0 = torch.cat([self.u0, self.v0], dim=1).contiguous() if two else self.u0
 
     def set_nu(self, nu):
         """Burgers viscosity: a float32 tensor in the reference (:96); a new value needs
@@ -252,14 +253,8 @@ class PhysicsInformedNN:
         # the three small data-term batches (IC, lower and upper boundary) go through net_u as ONE
         # batch: one forward and one vjp launch instead of three each (same values per point)
         n0, nb = self.x0.shape[0], self.x_lb.shape[0]
-        out_all = self.dnn(self._X_data)
-        out0, out_lb, out_ub = out_all[:n0], out_all[n0:n0 + nb], out_all[n0 + nb:]
-        loss0 = self._mse(out0, self.u0, self.v0) if two else self._mse(out0, self.u0)
-        if v.bc == "dirichlet":
-            loss_b = torch.mean(torch.square(out_lb)) + torch.mean(torch.square(out_ub))
-        else:
-            loss_b = sum(torch.mean(torch.square(out_lb[:, c:c + 1] - out_ub[:, c:c + 1]))
-                         for c in range(self.equation.nout))
+        loss0, loss_b = _DataLossFn.apply(self.dnn, self._X_data, self._tgt0, n0, nb, v.bc == "dirichlet",
+                                          self.dnn.grad_leaf())
 
         if side is None:
             loss_f = self.loss_f()
