@@ -170,3 +170,24 @@ def test_graph_replay_reproduces_eager_gradient(width):
         assert torch.isfinite(g).all()
         assert abs(float(loss.detach()) - loss_e) <= 1e-6 * abs(loss_e)
         assert float((g - g_e).norm() / g_e.norm()) < 1e-5
+
+
+def test_gnss_sliding_window_end_to_end(tmp_path):
+    """Two-output NLS/GNSS net at the reference's width 100 through the sliding-window driver on the HIP
+    path: captured Adam phase, device L-BFGS with the captured closure, window warm start, stitching of
+    u, v and h (NLS/sw-GNSS-adamW.py:262-404)."""
+    from pde_amd import drivers, scripts
+    x = np.linspace(-5, 5, 48)[:, None]
+    t = np.linspace(-2, 0, 11)[:, None]
+    uu = (1.0 / np.cosh(x.T - 0.3 * t)) * np.exp(1j * (0.5 * x.T + 0.4 * t))
+    cls = type("GSW", (scripts.gnss.sw.PhysicsInformedNN,), {"base_dir": str(tmp_path), "use_hip_graph": True})
+    models, (fu, fv, fh), errs = drivers.sliding_window(cls, [2, 100, 100, 100, 100, 2], x, t, uu, N0=32, Nb=16,
+                                                        Nf=3000, n_overlap=16, nIter=20, LBFGS_max_iter=5,
+                                                        log_name=None, rng=np.random.default_rng(0))
+    assert len(models) == 3 and fu.shape == fv.shape == fh.shape == (11 * 48, 1)
+    assert all(np.isfinite(e) for e in errs) and np.isfinite(fh).all()
+    assert all(type(m.optimizer_LBFGS).__module__ == "pde_amd.lbfgs" for m in models)
+    assert all(hasattr(m, "_lbfgs_graph") for m in models)
+    # the stitched field is what the reloaded window models predict
+    _, (fu2, fv2, fh2), errs2 = drivers.sliding_window(cls, [2, 100, 100, 100, 100, 2], x, t, uu, train=False)
+    assert np.allclose(fu2, fu, atol=1e-6) and np.allclose(fv2, fv, atol=1e-6) and np.allclose(errs2, errs, atol=1e-6)
