@@ -239,47 +239,89 @@ __global__ __launch_bounds__(64) void k_scalars(char *__restrict__ ws, int n, in
     // two-loop recursion on scalars.  Logical k = 0 oldest .. count-1 newest, j = sord[k].
     const bool staged = ldsn >= count && ldsn > 0;
     if (staged)
-        for (int idx = lane; idx < count * count; idx += 64) {
-            const int k = idx / count, m = idx - k * count;
-            SYl[k * ldsn + m] = SY[int64_t(sord[k]) * slots + sord[m]];
+        // eight loads in flight per lane (one at a time, every L2 round trip is on the critical path)
+        for (int base = lane; base < count * count; base += 64 * 8) {
+            double v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + 64 * u;
+                const int k = idx < count * count ? idx / count : 0, m = idx < count * count ? idx - k * count : 0;
+                dst[u] = idx < count * count ? k * ldsn + m : -1;
+                v[u] = SY[int64_t(sord[k]) * slots + sord[m]];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (dst[u] >= 0) SYl[dst[u]] = v[u];
         }
     for (int k = lane; k < count; k += 64) {
         rok[k] = ro[sord[k]];
         bk[k] = b[sord[k]];
     }
     __syncthreads();
-    //   al_k = ro_j ( -s_j.g - sum_{m>k} al_m s_j.y_m )
-    for (int k = count - 1; k >= 0; --k) {
-        const int j = sord[k];
-        double a = 0.0;
-        if (staged)
-            for (int m = k + 1 + lane; m < count; m += 64) a = fma(al[m], SYl[k * ldsn + m], a);
-        else
-            for (int m = k + 1 + lane; m < count; m += 64) a = fma(al[m], SY[int64_t(j) * slots + sord[m]], a);
-        a = wave_sum(a);
-        if (lane == 0) al[k] = rok[k] * (-bk[k] - a);
+    // Both loops are run "right-looking": lane l owns the rows k = l, l+64, ... and keeps their partial sums in
+    // registers; a step computes ONE scalar on its owner lane, publishes it through LDS, and every lane folds
+    // it into its own rows.  (The textbook left-looking form needs a wave-wide float64 reduction per step:
+    // twelve cross-lane shuffles on the critical path of each of the 2*count steps.)
+    constexpr int NK = (LB_MAX_HISTORY + 64) / 64;      // rows per lane, at most
+    auto sy = [&](int k, int m) -> double {             // s_k . y_m, logical indices
+        return staged ? SYl[k * ldsn + m] : SY[int64_t(sord[k]) * slots + sord[m]];
+    };
+    double acc[NK];
+    const int nk = (count + 63) >> 6;                   // rows per lane actually in use (wave-uniform)
+    //   al_m = ro_m ( -s_m.g - sum_{m'>m} al_m' s_m.y_m' ),  m = count-1 .. 0
+#pragma unroll
+    for (int i = 0; i < NK; ++i) acc[i] = 0.0;
+    for (int m = count - 1; m >= 0; --m) {
+        if (lane == (m & 63)) {
+            double a = 0.0;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) a = (i == (m >> 6)) ? acc[i] : a;
+            al[m] = rok[m] * (-bk[m] - a);
+        }
         __syncthreads();
+        const double alm = al[m];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int k = lane + 64 * i;
+            if (i < nk && k < m) acc[i] = fma(alm, sy(k, m), acc[i]);
+        }
     }
+    __syncthreads();
     //   be_k = ro_j y_j.r_k,  r_k = H(-g - sum_m al_m y_m) + sum_{m<k} cc_m s_m,  cc_k = al_k - be_k
     //   the y_j.(H q) part does not depend on earlier steps: all k in parallel first
     for (int k = lane; k < count; k += 64) {
         const int j = sord[k];
         double a = 0.0;
-        for (int m = 0; m < count; ++m) a = fma(al[m], YY[int64_t(j) * slots + sord[m]], a);
+        for (int m0 = 0; m0 < count; m0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = YY[int64_t(j) * slots + sord[m0 + u < count ? m0 + u : 0]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (m0 + u < count) a = fma(al[m0 + u], v[u], a);
+        }
         Ak[k] = H * (-c[j] - a);
     }
     __syncthreads();
-    for (int k = 0; k < count; ++k) {
-        const int j = sord[k];
-        double e = 0.0;
-        if (staged)
-            for (int m = lane; m < k; m += 64) e = fma(cc[m], SYl[m * ldsn + k], e);
-        else
-            for (int m = lane; m < k; m += 64) e = fma(cc[m], SY[int64_t(sord[m]) * slots + j], e);
-        e = wave_sum(e);
-        if (lane == 0) cc[k] = al[k] - rok[k] * (Ak[k] + e);
+#pragma unroll
+    for (int i = 0; i < NK; ++i) acc[i] = 0.0;
+    for (int m = 0; m < count; ++m) {
+        if (lane == (m & 63)) {
+            double e = 0.0;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) e = (i == (m >> 6)) ? acc[i] : e;
+            cc[m] = al[m] - rok[m] * (Ak[m] + e);
+        }
         __syncthreads();
+        const double ccm = cc[m];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int k = lane + 64 * i;
+            if (i < nk && k > m && k < count) acc[i] = fma(ccm, sy(m, k), acc[i]);
+        }
     }
+    __syncthreads();
     for (int k = lane; k < count; k += 64) {
         coefY[k] = -H * al[k];
         coefS[k] = cc[k];
