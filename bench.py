@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's points PER GPU; strong: the workload's points IN TOTAL "
+                         "(BASELINE: 7kdv N_f=1M on 1 and 8 GPUs; CH 10M over 8), sharded over the ranks")
     args = ap.parse_args()
 
     verbose = os.environ.get("PINN_BENCH_VERBOSE") == "1"
@@ -135,11 +138,18 @@ def main():
     from pde_amd import _native
 
     w = dict(WORKLOADS[args.workload])
-    if args.points:
-        w["n"] = args.points
-        w["name"] += " [points per GPU overridden: %d]" % args.points
-    n_local = w["n"]
-    n_global = n_local * world
+    if args.scaling == "strong":
+        # fixed total work: BASELINE's totals (CH is quoted at 10M over the node; the others at their N_f)
+        n_global = args.points or {"ch": 10_000_000}.get(args.workload, w["n"])
+        q, rem = divmod(n_global, world)
+        n_local = q + (1 if rank < rem else 0)
+        w["name"] += " [strong scaling: %d points in total over %d GPU(s)]" % (n_global, world)
+    else:
+        if args.points:
+            w["n"] = args.points
+            w["name"] += " [points per GPU overridden: %d]" % args.points
+        n_local = w["n"]
+        n_global = n_local * world
     fam = getattr(scripts, w["family"])
     cls = fam.PI.PhysicsInformedNN
     cls = type("BenchPINN", (cls,), {"kernel": {"auto": 0, "valu": 1, "mfma": 2}[args.kernel]})
@@ -272,13 +282,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (uniform collocation points, xavier-normal weights seed 1234)"
                     + ("" if backend == "nccl" else " - REHEARSAL over %s, not a measurement" % backend),
             "config": {"workload": w["name"], "equation": w["eq"], "layers": w["layers"],
-                       "points_per_gpu": n_local, "points_total": n_global,
+                       "points_per_gpu": n_local, "points_total": n_global, "scaling": args.scaling,
                        "parallelism": "dp%d over collocation points" % world,
                        "kernel": {1: "valu", 2: "mfma"}[eng.kernel_kind]},
             "allreduce_us": allreduce_us,

@@ -18,8 +18,11 @@
  *    row-major X_star -> x = X, t = X + 1, stride 2 (predict, :179-184);
  *  - `*_accum` outputs are ACCUMULATED into (+=), matching `.grad` semantics
  *    (callers zero first: optimizer.zero_grad(), :155,159);
- *  - kernels are enqueued on `stream` (a hipStream_t passed as void*) and the
- *    calls never synchronise the device;
+ *  - kernels are enqueued on `stream` (a hipStream_t passed as void*).  An entry
+ *    point allocates (hipMalloc / hipFree, which may synchronise the device and
+ *    cannot run under stream capture) ONLY when the call needs more workspace than
+ *    pinn_reserve() or any earlier call on the handle provided; size the handle
+ *    with pinn_reserve() at set-up and no later call allocates or synchronises;
  *  - return value: 0 = ok, negative = error (pinn_error_string()); nothing is
  *    printed and nothing aborts.
  *  - a handle's entry points must not be called concurrently from two host
@@ -36,7 +39,7 @@ extern "C" {
 #endif
 
 #define PINN_MAX_LAYERS 16
-#define PINN_MAX_WIDTH 128
+#define PINN_MAX_WIDTH 1024   /* any layer; the generic kernels also need 4*(P+2) <= 160 KB of LDS */
 #define PINN_MAX_OUT 2
 
 /* equation ids: which `net_f` body of the reference is evaluated */
@@ -49,11 +52,14 @@ enum {
     PINN_EQ_GNSS = 5     /* NLS/sw-GNSS-adamW.py:159-180   coef[0..2]=a,b,c (c=0: plain NLS)     */
 };
 
-/* kernel selection */
+/* kernel selection.  The FP32-MFMA kernels are instantiated for nets whose hidden layers all have
+ * the SAME width, one of 20, 50, 64, 100 (every width the reference's scripts use), with at least
+ * one hidden layer, as long as the weights fit LDS (e.g. not 6 x 64 / 4 x 100 with J >= 7 jets per
+ * neuron); every other shape runs the generic VALU kernels, which are ~20x slower. */
 enum {
-    PINN_KERNEL_AUTO = 0,    /* MFMA path when the hidden width is >= 32, else the VALU path */
-    PINN_KERNEL_VALU = 1,    /* generic one-point-per-lane VALU kernels                      */
-    PINN_KERNEL_MFMA = 2     /* 16-point-tile FP32-MFMA kernels (uniform hidden width <= 128) */
+    PINN_KERNEL_AUTO = 0,    /* the MFMA kernels when an instantiation covers the shape, else VALU     */
+    PINN_KERNEL_VALU = 1,    /* generic one-point-per-lane VALU kernels, any widths                    */
+    PINN_KERNEL_MFMA = 2     /* 16-point-tile FP32-MFMA kernels; PINN_ERR_UNSUPPORTED if not covered   */
 };
 
 typedef struct pinn_desc {
@@ -73,6 +79,11 @@ typedef struct pinn_handle pinn_handle;
  * Sequential(Scale, DNN) + the choice of net_f body (:77-81, :122-132). */
 int pinn_create(const pinn_desc *desc, pinn_handle **out);
 int pinn_destroy(pinn_handle *h);
+
+/* Size the handle's workspace for calls of up to n_max points (any entry point, any of them on the
+ * handle's equation or on plain net_u), so that none of them allocates afterwards (see Conventions).
+ * No counterpart in the reference (torch's caching allocator plays this role there). */
+int pinn_reserve(pinn_handle *h, int64_t n_max);
 
 /* shape queries: P = parameter count, J = jet components per output carried by
  * the residual kernels (K+1 x-orders then KT t-tangents), nf = residual

@@ -139,39 +139,14 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     return L;
 }
 
-// Timing ablations for kernel development (tools/ablate.sh): -DPINN_ABL_x=1 turns one cost centre into a
-// never-taken branch, so the build measures what that part costs.  Results are wrong with any of them on.
-#ifndef PINN_ABL_WACC
-#define PINN_ABL_WACC 0      // lock + read-add-write of the weight-gradient images
-#endif
-#ifndef PINN_ABL_SATOM
-#define PINN_ABL_SATOM 0     // the small (bias / tail / first / last layer) LDS atomics
-#endif
-#ifndef PINN_ABL_STLOAD
-#define PINN_ABL_STLOAD 0    // stash loads
-#endif
-#ifndef PINN_ABL_STSTORE
-#define PINN_ABL_STSTORE 0   // stash stores
-#endif
-#ifndef PINN_ABL_MFMA
-#define PINN_ABL_MFMA 0      // the MFMAs themselves
-#endif
-#ifndef PINN_CUT
-#define PINN_CUT 0
-#endif
 #ifndef PINN_ZPF
 #define PINN_ZPF 2           // reverse sweep: z of a neuron is requested this many neurons ahead
 #endif
-#define PINN_ADD_S(addr, v) do { if (!PINN_ABL_SATOM || rt_false) atomicAdd(addr, v); } while (0)
+#define PINN_ADD_S(addr, v) atomicAdd(addr, v)
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 {
-#if PINN_ABL_MFMA
-    c[0] += a * b;
-    return c;
-#else
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
 }
 
 // sum over the 16 lanes of a DPP row (= the 16 points of the tile); every lane gets the sum
@@ -202,30 +177,18 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // access, so no per-access 64-bit address is ever materialised (or hoisted and spilled).
 __device__ __forceinline__ void sb_store4(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats, f32x4 v)
 {
-#if PINN_ABL_STSTORE
-    if (voff >= 0) return;
-#endif
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff_floats * 4, 0);
 }
 __device__ __forceinline__ void sb_store1(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats, float v)
 {
-#if PINN_ABL_STSTORE
-    if (voff >= 0) return;
-#endif
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rs, voff, soff_floats * 4, 0);
 }
 __device__ __forceinline__ f32x4 sb_load4(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats)
 {
-#if PINN_ABL_STLOAD
-    if (voff >= 0) { const float v = __int_as_float(voff + soff_floats); return (f32x4){v, v, v, v}; }
-#endif
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff_floats * 4, 0));
 }
 __device__ __forceinline__ float sb_load1(__amdgpu_buffer_rsrc_t rs, int voff, int soff_floats)
 {
-#if PINN_ABL_STLOAD
-    if (voff >= 0) return __int_as_float(voff + soff_floats);
-#endif
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff_floats * 4, 0));
 }
 
@@ -290,8 +253,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     const int nf = (EQ == EQ_NONE) ? nout : (EQ == EQ_GNSS ? 2 : 1);
     const int P = d.P;
     const int tid = threadIdx.x;
-    const bool rt_false = d.P < 0;   // never true; only the ablation builds read it
-    (void)rt_false;
 
     // ---- stage the weights in LDS (zero padded) ----
     for (int i = tid; i < L.zero_end; i += MFMA_BLOCK) lds[i] = 0.0f;
@@ -520,10 +481,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         }
 
 
-#if PINN_CUT == 1
-        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
-          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
-#endif
         // ---- hidden -> hidden layers on the matrix cores, one jet component at a time, in place ----
         for (int l = 1; l <= n_lin - 2; ++l) {
             PINN_REFRESH();
@@ -650,10 +607,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
             }
         }
 
-#if PINN_CUT == 2
-        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
-          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
-#endif
         // ---- output layer (W -> nout), VALU + cross-quad reduction ----
         PINN_REFRESH();
         float D[MAXOUT][J], Tt[MAXOUT][J];
@@ -719,10 +672,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         }
 
 
-#if PINN_CUT == 3
-        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
-          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
-#endif
         // ---- output layer: bias gradient ----
         PINN_REFRESH();
 #pragma unroll
@@ -801,10 +750,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
             }
         }
 
-#if PINN_CUT == 4
-        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
-          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
-#endif
         // ---- Linear layers l = NH-1 .. 1 (hidden -> hidden), each followed by the tanh layer below it ----
         for (int l = NH - 1; l >= 1; --l) {
             PINN_REFRESH();
@@ -874,7 +819,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                             }
                             PINN_JB();
                         }
-                        if (!PINN_ABL_WACC || rt_false) {
+                        {
 #pragma unroll
                             for (int t = 0; t < GR; ++t) {
                                 // scalar offset of this row of tiles, re-derived here: formed once per layer the
@@ -951,7 +896,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                 }
                 // accumulator (To,Ti): lane (i = p, q) register r holds Wb[16To + 4q + r][16Ti + p]
                 if (WGLOBAL) {
-                    if (!PINN_ABL_WACC || rt_false) {
+                    {
                         // buffer atomics: one per-lane offset VGPR, everything else scalar
                         const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + 2) * 4, 0x00020000);
                         const int gvoff = (4 * q * W + p) * 4;
@@ -966,7 +911,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                                         __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(wacc[To][Ti][r], grs, gvoff,
                                                                                         gsoff + ((16 * To + r) * W + 16 * Ti) * 4, 0);
                     }
-                } else if (!PINN_ABL_WACC || rt_false) {
+                } else {
                     int *lk = (int *)(lds + L.locks) + (l - 1);
                     lds_lock(lk, lane);
 #pragma unroll
@@ -1010,10 +955,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                 }
             }
 
-#if PINN_CUT == 41
-            { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
-              for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
-#endif
             PINN_SB();
             PINN_REFRESH();
 
@@ -1087,10 +1028,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
             }
 
 
-#if PINN_CUT == 42
-            { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
-              for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
-#endif
             // tanh layer hl = l-1: A/At = adjoint of y_hl -> adjoint of z_hl, in place
             PINN_REFRESH();
             const int hl = l - 1;
@@ -1186,10 +1123,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         }
 
 
-#if PINN_CUT == 5
-        { for (int T = 0; T < NT; ++T) for (int j = 0; j < J; ++j) sb_store4(srs, vnat, (T * J + j) * TILE, A[T][j]);
-          for (int e = 0; e < RR; ++e) for (int j = 0; j < J; ++j) sb_store1(srs, vp, 2 * ZY + (e * J + j) * 16, At[e][j]); continue; }
-#endif
         // ---- first layer gradients from A/At = adjoint of z_0 ----
         PINN_REFRESH();
         PINN_XT_FETCH();
@@ -1278,14 +1211,6 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
 }
 
 // ------------------------------------------------------------------ host side
-struct MfmaPlan {
-    int grid = 0;
-    float *stash = nullptr;
-    size_t stash_bytes = 0;
-    float *slab = nullptr;
-    size_t slab_bytes = 0;
-};
-
 // hidden widths with an MFMA instantiation; anything else runs on the VALU path
 #if defined(PINN_DEV_KDV7_ONLY)
 #define PINN_MFMA_WIDTHS(X) X(50)
@@ -1352,67 +1277,49 @@ inline size_t mfma_stash_floats(const KDesc &kd, int J)
     }
 }
 
-inline int mfma_plan_create(MfmaPlan &pl, const KDesc &, int n_cu)
-{
-    pl.grid = n_cu;
-    // development knob: fewer workgroups (e.g. to shrink the stash footprint in experiments)
-    if (const char *g = getenv("PINN_MFMA_GRID")) {
-        const int v = atoi(g);
-        if (v > 0 && v < n_cu) pl.grid = v;
-    }
-    return 0;
-}
-
-inline void mfma_plan_destroy(MfmaPlan &pl)
-{
-    if (pl.stash) (void)hipFree(pl.stash);
-    if (pl.slab) (void)hipFree(pl.slab);
-    pl.stash = pl.slab = nullptr;
-}
-
 template <int EQ, int W, int MODE>
-int launch_mfma_t(MfmaPlan &pl, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
+int launch_mfma_t(float *stash, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
     const size_t ldsb = mfma_lds_bytes<W>(kd, EqTraits<EQ>::K + 1 + EqTraits<EQ>::KT);
     auto kern = k_mfma<EQ, W, MODE>;
     if (ldsb > 48 * 1024) {
         if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) {
             (void)hipGetLastError();
-            return -3;
+            return PINN_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<EQ>::KT)), ldsb, st, kd, a, pl.stash);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<EQ>::KT)), ldsb, st, kd, a, stash);
+    return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 
 template <int EQ, int MODE>
-int launch_mfma_w(MfmaPlan &pl, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
+int launch_mfma_w(float *stash, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
     switch (kd.widths[1]) {
-#define X(w) case w: return launch_mfma_t<EQ, w, MODE>(pl, kd, a, grid, st);
+#define X(w) case w: return launch_mfma_t<EQ, w, MODE>(stash, kd, a, grid, st);
         PINN_MFMA_WIDTHS(X)
 #undef X
-    default: return -2;
+    default: return PINN_ERR_UNSUPPORTED;
     }
 }
 
 template <int MODE>
-int launch_mfma_eq(MfmaPlan &pl, int eq, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
+int launch_mfma_eq(float *stash, int eq, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
     switch (eq) {
 #if defined(PINN_DEV_GNSS100_ONLY)
-    case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(pl, kd, a, grid, st);
+    case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(stash, kd, a, grid, st);
 #else
 #ifndef PINN_DEV_KDV7_ONLY
-    case EQ_NONE:    return launch_mfma_w<EQ_NONE, MODE>(pl, kd, a, grid, st);
-    case EQ_BURGERS: return launch_mfma_w<EQ_BURGERS, MODE>(pl, kd, a, grid, st);
-    case EQ_KDV5:    return launch_mfma_w<EQ_KDV5, MODE>(pl, kd, a, grid, st);
-    case EQ_CH:      return launch_mfma_w<EQ_CH, MODE>(pl, kd, a, grid, st);
-    case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(pl, kd, a, grid, st);
+    case EQ_NONE:    return launch_mfma_w<EQ_NONE, MODE>(stash, kd, a, grid, st);
+    case EQ_BURGERS: return launch_mfma_w<EQ_BURGERS, MODE>(stash, kd, a, grid, st);
+    case EQ_KDV5:    return launch_mfma_w<EQ_KDV5, MODE>(stash, kd, a, grid, st);
+    case EQ_CH:      return launch_mfma_w<EQ_CH, MODE>(stash, kd, a, grid, st);
+    case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(stash, kd, a, grid, st);
 #endif
-    case EQ_KDV7:    return launch_mfma_w<EQ_KDV7, MODE>(pl, kd, a, grid, st);
+    case EQ_KDV7:    return launch_mfma_w<EQ_KDV7, MODE>(stash, kd, a, grid, st);
 #endif
-    default: return -1;
+    default: return PINN_ERR_INVALID_DESC;
     }
 }
 

@@ -5,8 +5,8 @@
 // scratch laid out [slot][thread] so that each access is one coalesced
 // 256-B wave transaction; weights are wave-uniform reads; weight gradients
 // are reduced across the wave with DPP shuffles, accumulated per workgroup in
-// LDS and written as one partial slab per workgroup (summed by k_reduce_slabs,
-// so the result does not depend on atomic arrival order across workgroups).
+// LDS (float atomics from the four waves: arrival order, so the last bits differ run to run) and
+// written as one partial slab per workgroup; only the sum over workgroups (k_reduce_slabs) is fixed-order.
 //
 // Reference semantics: forward = Scale + DNN (7kdv/PI-7kdv3soliton.py:34-61),
 // jets = net_f's derivative chain (:122-132), reverse = loss.backward() (:111).

@@ -21,17 +21,24 @@ struct pinn_handle {
     int kernel;          // resolved PINN_KERNEL_*
     int device;
     int n_cu;
-    // workspace (grown on demand, never shrunk)
-    float *scratch = nullptr;
-    size_t scratch_bytes = 0;
-    float *slab = nullptr;
+    // workspace (sized by pinn_reserve or grown on demand, never shrunk)
+    float *jets = nullptr;       // VALU: per-thread jet scratch; MFMA: per-wave stash
+    size_t jets_bytes = 0;
+    float *slab = nullptr;       // per-workgroup partial [grid][P+2]
     size_t slab_bytes = 0;
-#ifdef PINN_WITH_MFMA
-    MfmaPlan mfma;
-#endif
+    int mfma_grid = 0;           // persistent grid of the MFMA kernels (<= n_cu)
 };
 
 namespace {
+
+// where a call's scratch memory comes from: the handle's own buffers (grown on demand) or a fixed
+// region that the grid is sized to fit
+struct FixedWs {
+    unsigned char *base;
+    size_t bytes;
+};
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int eq_orders(int eq, int nout, int *K, int *KT, int *nf)
 {
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *slab, int nbl
 }
 
 template <int EQ, int MODE>
-int launch_valu_t(pinn_handle *h, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
+int launch_valu_t(float *jets, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
     const size_t lds = (MODE == MODE_FWD) ? 0 : (size_t)(kd.P + 2) * sizeof(float);
     auto kern = k_valu<EQ, MODE>;
@@ -105,109 +112,118 @@ int launch_valu_t(pinn_handle *h, const KDesc &kd, const CallArgs &a, int grid, 
             return PINN_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(VALU_BLOCK), lds, st, kd, a, h->scratch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(VALU_BLOCK), lds, st, kd, a, jets);
     return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 
 template <int MODE>
-int launch_valu_eq(pinn_handle *h, int eq, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
+int launch_valu_eq(float *jets, int eq, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
     switch (eq) {
-    case PINN_EQ_NONE:    return launch_valu_t<EQ_NONE, MODE>(h, kd, a, grid, st);
-    case PINN_EQ_BURGERS: return launch_valu_t<EQ_BURGERS, MODE>(h, kd, a, grid, st);
-    case PINN_EQ_KDV5:    return launch_valu_t<EQ_KDV5, MODE>(h, kd, a, grid, st);
-    case PINN_EQ_KDV7:    return launch_valu_t<EQ_KDV7, MODE>(h, kd, a, grid, st);
-    case PINN_EQ_CH:      return launch_valu_t<EQ_CH, MODE>(h, kd, a, grid, st);
-    case PINN_EQ_GNSS:    return launch_valu_t<EQ_GNSS, MODE>(h, kd, a, grid, st);
+    case PINN_EQ_NONE:    return launch_valu_t<EQ_NONE, MODE>(jets, kd, a, grid, st);
+    case PINN_EQ_BURGERS: return launch_valu_t<EQ_BURGERS, MODE>(jets, kd, a, grid, st);
+    case PINN_EQ_KDV5:    return launch_valu_t<EQ_KDV5, MODE>(jets, kd, a, grid, st);
+    case PINN_EQ_KDV7:    return launch_valu_t<EQ_KDV7, MODE>(jets, kd, a, grid, st);
+    case PINN_EQ_CH:      return launch_valu_t<EQ_CH, MODE>(jets, kd, a, grid, st);
+    case PINN_EQ_GNSS:    return launch_valu_t<EQ_GNSS, MODE>(jets, kd, a, grid, st);
     default: return PINN_ERR_INVALID_DESC;
     }
 }
 
-// one residual-type call on the VALU path
-int run_valu(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, float *loss_accum, hipStream_t st)
+// What one call needs: the grid it would like and, per workgroup of it, the bytes of jet scratch
+// (VALU: [slot][thread] jets; MFMA: the per-wave stash of the reverse sweep) and of partial slab.
+struct Need {
+    int grid;
+    size_t jets_per_wg, slab_per_wg;
+    int nf;
+    bool zero_slab;     // wide MFMA layers add into the slab with memory-side atomics: it has to start at zero
+};
+
+int call_need(const pinn_handle *h, int eq, int mode, long long n, Need *nd)
 {
     int K, KT, nf;
     if (eq_orders(eq, h->kd.nout, &K, &KT, &nf)) return PINN_ERR_INVALID_DESC;
     const int J = K + 1 + KT;
-    const long long need_blocks = (a.n + VALU_BLOCK - 1) / VALU_BLOCK;
-    const int grid = (int)(need_blocks < h->n_cu ? need_blocks : h->n_cu);
-    const ValuSlots sl = valu_slots(h->kd, J);
-    int rc = ensure(&h->scratch, &h->scratch_bytes, (size_t)sl.total * grid * VALU_BLOCK * sizeof(float));
-    if (rc) return rc;
-    if (mode != MODE_FWD) {
-        rc = ensure(&h->slab, &h->slab_bytes, (size_t)grid * (h->kd.P + 2) * sizeof(float));
-        if (rc) return rc;
-        a.slab = h->slab;
-    }
-    switch (mode) {
-    case MODE_FWD:  rc = launch_valu_eq<MODE_FWD>(h, eq, h->kd, a, grid, st); break;
-    case MODE_VJP:  rc = launch_valu_eq<MODE_VJP>(h, eq, h->kd, a, grid, st); break;
-    default:        rc = launch_valu_eq<MODE_LOSS>(h, eq, h->kd, a, grid, st); break;
-    }
-    if (rc) return rc;
-    if (mode != MODE_FWD) {
-        const int rb = (h->kd.P + 2 + 63) / 64;
-        hipLaunchKernelGGL(k_reduce_slabs, dim3(rb), dim3(256), 0, st, h->slab, grid, h->kd.P, grad_accum,
-                           loss_accum, nf);
-        if (hipGetLastError() != hipSuccess) return PINN_ERR_HIP;
-    }
-    return PINN_OK;
-}
-
+    nd->nf = nf;
+    nd->zero_slab = false;
+    nd->slab_per_wg = (mode != MODE_FWD) ? (size_t)(h->kd.P + 2) * sizeof(float) : 0;
 #ifdef PINN_WITH_MFMA
-// one residual-type call on the MFMA path
-int run_mfma(MfmaPlan &pl, const KDesc &kd, int eq, int mode, CallArgs a, float *grad_accum, float *loss_accum,
-             hipStream_t st)
-{
-    int K, KT, nf;
-    if (eq_orders(eq, kd.nout, &K, &KT, &nf)) return PINN_ERR_INVALID_DESC;
-    const int J = K + 1 + KT;
-    const long long ntiles = (a.n + 15) / 16;
-    const int waves = mfma_waves(kd, J);
-    const long long need_blocks = (ntiles + waves - 1) / waves;
-    const int grid = (int)(need_blocks < pl.grid ? need_blocks : pl.grid);
-    int rc;
-    if (mode != MODE_FWD) {
-        const size_t per_wave = mfma_stash_floats(kd, J) * sizeof(float);
-        rc = ensure(&pl.stash, &pl.stash_bytes, per_wave * grid * waves);
-        if (rc) return rc;
-        const size_t slab_bytes = (size_t)grid * (kd.P + 2) * sizeof(float);
-        rc = ensure(&pl.slab, &pl.slab_bytes, slab_bytes);
-        if (rc) return rc;
-        a.slab = pl.slab;
-        // wide layers accumulate into their slab with atomics: it has to start at zero
-        if (mfma_wglobal(kd)) {
-            const long long nfl = (long long)(slab_bytes / sizeof(float));
-            const int zb = (int)((nfl + 256 * 8 - 1) / (256 * 8) < 2048 ? (nfl + 256 * 8 - 1) / (256 * 8) : 2048);
-            hipLaunchKernelGGL(k_zero_floats, dim3(zb > 0 ? zb : 1), dim3(256), 0, st, pl.slab, nfl);
-        }
+    if (h->kernel == PINN_KERNEL_MFMA) {
+        const long long ntiles = (n + 15) / 16;
+        const int waves = mfma_waves(h->kd, J);
+        const long long need_blocks = (ntiles + waves - 1) / waves;
+        nd->grid = (int)(need_blocks < h->mfma_grid ? need_blocks : h->mfma_grid);
+        nd->jets_per_wg = (mode != MODE_FWD) ? mfma_stash_floats(h->kd, J) * sizeof(float) * waves : 0;
+        nd->zero_slab = (mode != MODE_FWD) && mfma_wglobal(h->kd);
+        return PINN_OK;
     }
-    switch (mode) {
-    case MODE_FWD:  rc = launch_mfma_eq<MODE_FWD>(pl, eq, kd, a, grid, st); break;
-    case MODE_VJP:  rc = launch_mfma_eq<MODE_VJP>(pl, eq, kd, a, grid, st); break;
-    default:        rc = launch_mfma_eq<MODE_LOSS>(pl, eq, kd, a, grid, st); break;
-    }
-    if (rc) return rc;
-    if (mode != MODE_FWD) {
-        const int rb = (kd.P + 2 + 63) / 64;
-        hipLaunchKernelGGL(k_reduce_slabs, dim3(rb), dim3(256), 0, st, pl.slab, grid, kd.P, grad_accum, loss_accum, nf);
-        if (hipGetLastError() != hipSuccess) return PINN_ERR_HIP;
-    }
+#endif
+    const long long need_blocks = (n + VALU_BLOCK - 1) / VALU_BLOCK;
+    nd->grid = (int)(need_blocks < h->n_cu ? need_blocks : h->n_cu);
+    nd->jets_per_wg = (size_t)valu_slots(h->kd, J).total * VALU_BLOCK * sizeof(float);
     return PINN_OK;
 }
-#endif
 
-int run(pinn_handle *h, int eq, int mode, const CallArgs &a, float *grad_accum, float *loss_accum, void *stream)
+// one call of any kind on either kernel family
+int run(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, float *loss_accum, void *stream,
+        const FixedWs *fixed = nullptr)
 {
     if (!h) return PINN_ERR_NULL;
     if (!a.theta || !a.x || !a.t) return PINN_ERR_NULL;
     if (a.n < 0 || a.stride < 1) return PINN_ERR_INVALID_DESC;
     if (a.n == 0) return PINN_OK;
     hipStream_t st = (hipStream_t)stream;
+    Need nd;
+    int rc = call_need(h, eq, mode, a.n, &nd);
+    if (rc) return rc;
+    int grid = nd.grid;
+    float *jets, *slab;
+    if (fixed) {
+        // size the (persistent) grid to the fixed region; every kernel strides its tiles over whatever grid it gets
+        const size_t per_wg = nd.jets_per_wg + nd.slab_per_wg;
+        const long long fit = per_wg ? (long long)((fixed->bytes - 256) / per_wg) : grid;
+        if (fit < 1) return PINN_ERR_UNSUPPORTED;
+        if (fit < grid) grid = (int)fit;
+        jets = (float *)fixed->base;
+        slab = (float *)(fixed->base + align256(nd.jets_per_wg * grid));
+    } else {
+        rc = ensure(&h->jets, &h->jets_bytes, nd.jets_per_wg * grid);
+        if (rc) return rc;
+        rc = ensure(&h->slab, &h->slab_bytes, nd.slab_per_wg * grid);
+        if (rc) return rc;
+        jets = h->jets;
+        slab = h->slab;
+    }
+    if (mode != MODE_FWD) a.slab = slab;
+    if (nd.zero_slab) {
+        const long long nfl = (long long)(nd.slab_per_wg / sizeof(float)) * grid;
+        const long long zb = (nfl + 256 * 8 - 1) / (256 * 8);
+        hipLaunchKernelGGL(k_zero_floats, dim3(zb < 1 ? 1 : (zb < 2048 ? (int)zb : 2048)), dim3(256), 0, st, slab, nfl);
+    }
 #ifdef PINN_WITH_MFMA
-    if (h->kernel == PINN_KERNEL_MFMA) return run_mfma(h->mfma, h->kd, eq, mode, a, grad_accum, loss_accum, st);
+    if (h->kernel == PINN_KERNEL_MFMA) {
+        switch (mode) {
+        case MODE_FWD:  rc = launch_mfma_eq<MODE_FWD>(jets, eq, h->kd, a, grid, st); break;
+        case MODE_VJP:  rc = launch_mfma_eq<MODE_VJP>(jets, eq, h->kd, a, grid, st); break;
+        default:        rc = launch_mfma_eq<MODE_LOSS>(jets, eq, h->kd, a, grid, st); break;
+        }
+    } else
 #endif
-    return run_valu(h, eq, mode, a, grad_accum, loss_accum, st);
+    {
+        switch (mode) {
+        case MODE_FWD:  rc = launch_valu_eq<MODE_FWD>(jets, eq, h->kd, a, grid, st); break;
+        case MODE_VJP:  rc = launch_valu_eq<MODE_VJP>(jets, eq, h->kd, a, grid, st); break;
+        default:        rc = launch_valu_eq<MODE_LOSS>(jets, eq, h->kd, a, grid, st); break;
+        }
+    }
+    if (rc) return rc;
+    if (mode != MODE_FWD) {
+        // fixed-order sum of the per-workgroup partials into the caller's buffers
+        const int rb = (h->kd.P + 2 + 63) / 64;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(rb), dim3(256), 0, st, slab, grid, h->kd.P, grad_accum, loss_accum, nd.nf);
+        if (hipGetLastError() != hipSuccess) return PINN_ERR_HIP;
+    }
+    return PINN_OK;
 }
 
 }  // namespace
@@ -221,7 +237,7 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     if (desc->n_lin < 2 || desc->n_lin > PINN_MAX_LAYERS) return PINN_ERR_INVALID_DESC;
     if (desc->widths[0] != 2) return PINN_ERR_INVALID_DESC;
     for (int l = 1; l <= desc->n_lin; ++l)
-        if (desc->widths[l] < 1 || desc->widths[l] > 1024) return PINN_ERR_INVALID_DESC;
+        if (desc->widths[l] < 1 || desc->widths[l] > PINN_MAX_WIDTH) return PINN_ERR_INVALID_DESC;
     const int nout = desc->widths[desc->n_lin];
     if (nout > PINN_MAX_OUT) return PINN_ERR_INVALID_DESC;
     if (!(desc->ub[0] > desc->lb[0]) || !(desc->ub[1] > desc->lb[1])) return PINN_ERR_INVALID_DESC;
@@ -269,12 +285,7 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     if (kernel != PINN_KERNEL_MFMA && kernel != PINN_KERNEL_VALU) { delete h; return PINN_ERR_INVALID_DESC; }
     if (kernel == PINN_KERNEL_VALU && (size_t)(kd.P + 2) * sizeof(float) > 160 * 1024) { delete h; return PINN_ERR_UNSUPPORTED; }
     h->kernel = kernel;
-#ifdef PINN_WITH_MFMA
-    if (kernel == PINN_KERNEL_MFMA) {
-        const int rc = mfma_plan_create(h->mfma, kd, h->n_cu);
-        if (rc) { delete h; return rc; }
-    }
-#endif
+    h->mfma_grid = h->n_cu;      // persistent kernels: at most one workgroup per CU
     *out = h;
     return PINN_OK;
 }
@@ -282,11 +293,8 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
 int pinn_destroy(pinn_handle *h)
 {
     if (!h) return PINN_OK;
-    if (h->scratch) (void)hipFree(h->scratch);
+    if (h->jets) (void)hipFree(h->jets);
     if (h->slab) (void)hipFree(h->slab);
-#ifdef PINN_WITH_MFMA
-    if (h->kernel == PINN_KERNEL_MFMA) mfma_plan_destroy(h->mfma);
-#endif
     delete h;
     return PINN_OK;
 }
@@ -311,6 +319,26 @@ int pinn_forward_vjp(pinn_handle *h, const float *theta, const float *x, const f
     if (!gbar || !grad_theta_accum) return PINN_ERR_NULL;
     CallArgs a{theta, x, t, stride, n, gbar, 0.0f, nullptr, nullptr, nullptr};
     return run(h, PINN_EQ_NONE, MODE_VJP, a, grad_theta_accum, nullptr, stream);
+}
+
+int pinn_reserve(pinn_handle *h, int64_t n_max)
+{
+    if (!h) return PINN_ERR_NULL;
+    if (n_max < 0) return PINN_ERR_INVALID_DESC;
+    if (n_max == 0) return PINN_OK;
+    size_t jets = 0, slab = 0;
+    const int eqs[2] = {h->desc.eq, PINN_EQ_NONE};
+    for (int e = 0; e < 2; ++e)
+        for (int mode = MODE_FWD; mode <= MODE_LOSS; ++mode) {
+            Need nd;
+            const int rc = call_need(h, eqs[e], mode, n_max, &nd);
+            if (rc) return rc;
+            if (nd.jets_per_wg * nd.grid > jets) jets = nd.jets_per_wg * nd.grid;
+            if (nd.slab_per_wg * nd.grid > slab) slab = nd.slab_per_wg * nd.grid;
+        }
+    int rc = ensure(&h->jets, &h->jets_bytes, jets);
+    if (rc) return rc;
+    return ensure(&h->slab, &h->slab_bytes, slab);
 }
 
 int pinn_residual_fwd(pinn_handle *h, const float *theta, const float *x, const float *t, int64_t stride,

@@ -131,11 +131,28 @@ class _ResidualFn(torch.autograd.Function):
         return None, None, None, None, g
 
 
+def all_reduce_sum(buf, group):
+    """The closure's one collective: SUM over the ranks of `group`, in place.  On RCCL (backend "nccl")
+    the device buffer goes straight in.  A gloo group (CPU rehearsals, several ranks sharing one GPU in
+    the tests) gets it staged through the host: gloo reduces host memory anyway."""
+    import torch.distributed as dist
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
 class _ResidualLossFn(torch.autograd.Function):
     """loss_f = sum_c mean_p f_c^2 in ONE fused kernel pass that also produces
     d loss_f / d theta (the reference's loss_f + its share of loss.backward(),
-    :107-108,111).  With a process group the local partial sums of the shard are
-    all-reduced once: [grad (P floats), sum f_c^2 (nf floats)]."""
+    :107-108,111).  `n_global` is the number of collocation points over ALL ranks: the value and
+    the gradient are this rank's share of the global mean.  With `group` the shares are summed here
+    ([grad (P floats), sum f_c^2 (nf floats)]: the collocation term alone, as bench.py times it);
+    a sharded training closure passes group=None and all-reduces the WHOLE closure once instead
+    (PhysicsInformedNN._loss_terms_sharded)."""
 
     @staticmethod
     def forward(ctx, net, engine, x, t, n_global, group, leaf):
@@ -144,7 +161,7 @@ class _ResidualLossFn(torch.autograd.Function):
         if x.numel() > 0:
             engine.loss_grad(theta, x, t, 1.0 / float(n_global), buf[engine.P:], buf[:engine.P])
         if group is not None:
-            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
+            all_reduce_sum(buf, group)
         ctx.net = net
         ctx.grad_flat = buf[:engine.P]
         return buf[engine.P:].sum() / float(n_global)
@@ -162,6 +179,7 @@ class NetU(torch.nn.Sequential):
         super().__init__(Scale(lb, ub, device), DNN(layers))
         self.layer_sizes = list(layers)
         self._device = device
+        self._collect = None
         self[1].apply(xavier)
         self._flatten_params()
         # engine for plain forward / data-loss terms (equation "none")
@@ -185,17 +203,32 @@ class NetU(torch.nn.Sequential):
         """The autograd leaf a native op takes as its parameter input: a fresh alias of the flat buffer
         per call (no kernel), so that its gradient accumulation runs on the stream the op runs on —
         a cached leaf keeps the stream of its first use, which breaks HIP-graph capture on another one."""
+        if self._collect is not None:
+            return self._collect
         leaf = self.flat_theta().detach().requires_grad_(True)
         leaf.register_post_accumulate_grad_hook(self._distribute_grad)
         return leaf
 
+    def collect_leaf(self):
+        """Sharded closures (PhysicsInformedNN._loss_terms_sharded): ONE hook-free leaf that every native op
+        of the closure takes until `end_collect()`, so that `torch.autograd.grad(loss, leaf)` yields the
+        rank-local flat gradient of the whole closure — which is all-reduced before any parameter sees it."""
+        self._collect = self.flat_theta().detach().requires_grad_(True)
+        return self._collect
+
+    def end_collect(self):
+        self._collect = None
+
     def _distribute_grad(self, leaf):
+        g = leaf.grad
+        leaf.grad = None
+        self.distribute_flat_grad(g)
+
+    def distribute_flat_grad(self, g):
         """Runs once per native op and backward pass: every parameter gets its slice of the op's flat gradient.  `.grad` is None (after zero_grad(set_to_none=True)): the
         slices become the `.grad` tensors, no kernel at all.  `.grad` are consecutive views of one
         buffer (pde_amd.lbfgs.LBFGS keeps them so): one flat add.  Otherwise: one add per parameter,
         the usual accumulating semantics."""
-        g = leaf.grad
-        leaf.grad = None
         params = self.param_list
         first = params[0].grad
         if first is not None:

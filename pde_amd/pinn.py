@@ -61,6 +61,7 @@ class PhysicsInformedNN:
     default_device = None            # None -> current CUDA device
     kernel = KERNEL_AUTO
     use_hip_graph = False            # train(): replay the Adam phase from a captured HIP graph (single process)
+    hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
     lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (one launch per direction); "torch": torch.optim.LBFGS
     lbfgs_kernels_factory = None     # test hook: callable(n, history) -> stand-in for the L-BFGS launches
     engine_factory = None            # test hook: callable(equation|None, layers, lb, ub, device) -> engine
@@ -189,6 +190,14 @@ class PhysicsInformedNN:
                                   torch.cat([self.x_lb, self.tb], dim=1),
                                   torch.cat([self.x_ub, self.tb], dim=1)], dim=0).contiguous()
         self._tgt0 = torch.cat([self.u0, self.v0], dim=1).contiguous() if two else self.u0
+        # size the engines' workspaces once: no closure allocates (or synchronises) afterwards, so the
+        # first one is as capturable into a HIP graph as any other (include/pinnjet.h, pinn_reserve)
+        n_data = max(self._X_data.shape[0], self.x1.shape[0] if self.x1 is not None else 0,
+                     self.X_prev.shape[0] if self.X_prev is not None else 0)
+        if hasattr(self.engine_f, "reserve"):
+            self.engine_f.reserve(self.xf.shape[0])
+        if hasattr(self.dnn.engine, "reserve"):
+            self.dnn.engine.reserve(n_data)
 
     def set_nu(self, nu):
         """Burgers viscosity: a float32 tensor in the reference (:96); a new value needs
@@ -239,10 +248,12 @@ class PhysicsInformedNN:
         third of a closure's GPU time.  The two branches are back-propagated separately (data first,
         then the collocation term, ordered by stream waits because both add into the same flat
         gradient); the returned `loss` is then a detached sum."""
+        if self.group is not None:
+            return self._loss_terms_sharded()
         v = self.variant
         two = self.equation.nout == 2
         side = cur = None
-        if overlap and self.group is None and torch.device(self.device).type == "cuda":
+        if overlap and torch.device(self.device).type == "cuda":
             cur = torch.cuda.current_stream(self.device)
             if getattr(self, "_side_stream", None) is None:
                 self._side_stream = torch.cuda.Stream(device=self.device)
@@ -259,14 +270,7 @@ class PhysicsInformedNN:
         if side is None:
             loss_f = self.loss_f()
 
-        loss1 = None
-        loss_prev = 0
-        if v.style == "bc" and self.u1 is not None:
-            out1 = self.dnn(torch.cat([self.x1, self.t1], dim=1))
-            loss1 = self._mse(out1, self.u1, self.v1) if two else self._mse(out1, self.u1)
-        if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
-            outp = self.dnn(self.X_prev)
-            loss_prev = self._mse(outp, self.u_prev, self.v_prev) if two else self._mse(outp, self.u_prev)
+        loss1, loss_prev = self._extra_data_terms()
 
         if side is None:
             loss = loss0 + loss_b + loss_f
@@ -289,9 +293,74 @@ class PhysicsInformedNN:
             loss = loss_d.detach() + loss_f.detach()
         return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev}
 
+    def _extra_data_terms(self):
+        """loss1 of the bc classes (7kdv/bc-7kdv3soliton.py:251-253) and loss_prev of the sw classes
+        (7kdv/sw-73.py:132-142): (None | tensor, 0 | tensor) like the reference's locals."""
+        v = self.variant
+        two = self.equation.nout == 2
+        loss1 = None
+        loss_prev = 0
+        if v.style == "bc" and self.u1 is not None:
+            out1 = self.dnn(torch.cat([self.x1, self.t1], dim=1))
+            loss1 = self._mse(out1, self.u1, self.v1) if two else self._mse(out1, self.u1)
+        if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
+            outp = self.dnn(self.X_prev)
+            loss_prev = self._mse(outp, self.u_prev, self.v_prev) if two else self._mse(outp, self.u_prev)
+        return loss1, loss_prev
+
+    def _loss_terms_sharded(self):
+        """The closure of a sharded run: every rank evaluates the collocation term on ITS
+        shard (value and gradient already scaled by 1/N_global), rank 0 alone evaluates the data terms
+        (IC, boundary, loss1, loss_prev: at most a few thousand points), and ONE all-reduce(SUM) of
+        [flat gradient (P), loss0, loss_b, loss_f, loss1, loss_prev] gives every rank the same bits for
+        everything an optimizer reads: the float32 sums inside the kernels depend on wave arrival order
+        (LDS / memory-side float adds), so nothing a rank computed by itself may reach `.grad` or the
+        returned loss.  Adam/AdamW (elementwise) and pde_amd.lbfgs.LBFGS (fixed-order reductions) then
+        make identical updates and identical line-search decisions: the replicas stay bit-identical
+        without a broadcast, and the closure counts agree (no mismatched collectives)."""
+        import torch.distributed as dist
+        from .nn import all_reduce_sum
+        v = self.variant
+        P = self.engine_f.P
+        leaf = self.dnn.collect_leaf()
+        try:
+            loss_f = _ResidualLossFn.apply(self.dnn, self.engine_f, self.xf, self.tf, self.n_f_global, None, leaf)
+            zero = torch.zeros((), dtype=torch.float32, device=self.device)
+            loss0 = loss_b = zero
+            loss1, loss_prev = None, 0
+            if dist.get_rank(self.group) == 0:
+                n0, nb = self.x0.shape[0], self.x_lb.shape[0]
+                loss0, loss_b = _DataLossFn.apply(self.dnn, self._X_data, self._tgt0, n0, nb, v.bc == "dirichlet", leaf)
+                loss1, loss_prev = self._extra_data_terms()
+            has1 = v.style == "bc" and self.u1 is not None
+            hasp = v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0
+            local = loss0 + loss_b + loss_f
+            if loss1 is not None:
+                local = local + loss1
+            if torch.is_tensor(loss_prev):
+                local = local + loss_prev
+            g, = torch.autograd.grad(local, leaf)
+        finally:
+            self.dnn.end_collect()
+        buf = torch.empty(P + 5, dtype=torch.float32, device=self.device)
+        buf[:P] = g
+        buf[P:] = torch.stack([loss0.detach(), loss_b.detach(), loss_f.detach(),
+                               loss1.detach() if loss1 is not None else zero,
+                               loss_prev.detach() if torch.is_tensor(loss_prev) else zero])
+        all_reduce_sum(buf, self.group)
+        self.dnn.distribute_flat_grad(buf[:P])
+        t = buf[P:]
+        loss = t[0] + t[1] + t[2]
+        if has1:
+            loss = loss + t[3]
+        if hasp:
+            loss = loss + t[4]
+        return {"loss": loss, "loss0": t[0], "loss_b": t[1], "loss_f": t[2], "loss1": t[3] if has1 else None,
+                "loss_prev": t[4] if hasp else 0}
+
     def check_replicas(self):
         """Sharded runs keep the weights identical on every rank WITHOUT a broadcast: every rank applies
-        the same optimizer update to the same all-reduced gradient.  This verifies it:
+        the same optimizer update to the same all-reduced closure result (_loss_terms_sharded).  This verifies it:
         the element-wise MIN and MAX over ranks of [sum theta, sum theta^2] must coincide.  Called with
         the every-100-iterations log line; raises on every rank if the replicas have drifted apart."""
         if self.group is None:
@@ -404,7 +473,10 @@ class PhysicsInformedNN:
         graph after a few eager iterations and replayed; the host only touches the device for the
         reference's every-100-iterations log line.  Same kernels in the same order as the eager loop
         (Adam's bias corrections are evaluated on the device in fp32 instead of in Python doubles).
-        Returns the number of iterations done; on any capture failure the caller continues eagerly."""
+        Returns the number of iterations done.  A capture failure raises (a broken capture must not
+        turn into a silent slow run); with `hip_graph_fallback = True` it is reported and the caller
+        continues eagerly with the SAME optimizer (capturable Adam also steps eagerly), so the moments
+        and step count of the warm-up iterations are kept."""
         v = self.variant
         kw = dict(capturable=True)
         if v.optimizer == "adamw":
@@ -431,11 +503,12 @@ class PhysicsInformedNN:
             with torch.cuda.graph(graph):
                 terms = self._loss_terms(overlap=True)
                 opt.step()
-        except Exception as ex:                         # noqa: BLE001 - any capture problem -> eager loop
-            print("HIP-graph capture of the training step failed (%s); continuing eagerly" % (ex,))
+        except Exception as ex:                         # noqa: BLE001
             torch.cuda.synchronize(self.device)
-            self.optimizer_Adam = torch.optim.AdamW(params, weight_decay=v.weight_decay) if v.optimizer == "adamw" \
-                else torch.optim.Adam(params)
+            if not self.hip_graph_fallback:
+                raise RuntimeError("HIP-graph capture of the training step failed (set hip_graph_fallback = True "
+                                   "to continue eagerly instead): %s" % (ex,)) from ex
+            print("HIP-graph capture of the training step failed (%s); continuing eagerly" % (ex,))
             return done
         t_rep, n_rep = time.time(), nIter - done
         while done < nIter:
@@ -452,7 +525,7 @@ class PhysicsInformedNN:
         """The L-BFGS closure (zero the flat gradient, the loss terms, loss.backward()) captured once
         into a HIP graph and replayed per evaluation: the line search moves the weights in place, so
         every address the graph holds stays valid.  Needs pde_amd.lbfgs.LBFGS (its `.grad` are views
-        of one static buffer).  Returns None when the capture fails."""
+        of one static buffer).  A capture failure raises unless `hip_graph_fallback` is set (then: None)."""
         opt = self.optimizer_LBFGS
         try:
             side = torch.cuda.Stream(device=self.device)
@@ -468,9 +541,12 @@ class PhysicsInformedNN:
             with torch.cuda.graph(graph):
                 opt.flat_grad().zero_()
                 terms = self._loss_terms(overlap=True)
-        except Exception as ex:                         # noqa: BLE001 - any capture problem -> eager closure
-            print("HIP-graph capture of the L-BFGS closure failed (%s); continuing eagerly" % (ex,))
+        except Exception as ex:                         # noqa: BLE001
             torch.cuda.synchronize(self.device)
+            if not self.hip_graph_fallback:
+                raise RuntimeError("HIP-graph capture of the L-BFGS closure failed (set hip_graph_fallback = True "
+                                   "to continue eagerly instead): %s" % (ex,)) from ex
+            print("HIP-graph capture of the L-BFGS closure failed (%s); continuing eagerly" % (ex,))
             return None
         self._lbfgs_graph = graph
 

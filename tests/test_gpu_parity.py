@@ -242,6 +242,30 @@ def test_full_size_properties(kname, kernel):
     assert rel(o3.cpu().numpy(), lin) < 1e-4
 
 
+@pytest.mark.parametrize("kname,kernel", KINDS)
+@pytest.mark.parametrize("name", ["kdv7_3sol_ckpt", "gnss_w100_ckpt"])
+def test_run_to_run_agreement(name, kname, kernel):
+    """The guarantee the kernels give for repeated launches on the same inputs: agreement to float32
+    summation order, NOT bit equality (partial sums inside a workgroup are added in wave arrival order:
+    LDS read-add-write under a lock, few-lane LDS atomics, memory-side float adds).
+    Whatever must be bit-identical across ranks goes through the closure's all-reduce instead."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    eng = engine_for(g, kernel)
+    rng = np.random.default_rng(5)
+    n = 20_000
+    X = (g["lb"] + (g["ub"] - g["lb"]) * rng.random((n, 2))).astype(np.float32)
+    theta, x, t = cu(g["theta"]), cu(X[:, 0]), cu(X[:, 1])
+    runs = []
+    for _ in range(3):
+        buf = torch.zeros(eng.P + eng.nf, device=dev())
+        eng.loss_grad(theta, x, t, 1.0 / n, buf[eng.P:], buf[:eng.P])
+        torch.cuda.synchronize()
+        runs.append(buf.cpu().numpy().astype(np.float64))
+    for r in runs[1:]:
+        assert rel(r[:eng.P], runs[0][:eng.P]) < 1e-6
+        assert rel(r[eng.P:], runs[0][eng.P:]) < 1e-6
+
+
 def _load_theta(model, theta):
     off = 0
     with torch.no_grad():
