@@ -107,6 +107,22 @@ int pinn_forward_vjp(pinn_handle *h, const float *theta, const float *x, const f
                      int64_t stride, int64_t n, const float *gbar, float *grad_theta_accum,
                      void *stream);
 
+/* pinn_forward_vjp for callers that cannot allocate — code under HIP-graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments
+ * and result as pinn_forward_vjp (the data-loss terms are its use: they have at most a few thousand
+ * points), but the kernels' scratch (per-wave stash / per-thread jets and the per-workgroup partial
+ * slabs) lives in ONE static device array of PINN_STATIC_SCRATCH_BYTES that every GPU the library
+ * runs on holds until the process ends; the call never allocates, frees or synchronises.  The grid is
+ * sized to what fits the array.  n > PINN_STATIC_MAX_POINTS, or a net of which not even one
+ * workgroup's scratch fits, is rejected with PINN_ERR_TOO_LARGE.  The handle's device must be current.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams,
+ * two host threads, two handles) race; run them one after the other on one stream. */
+#define PINN_STATIC_SCRATCH_BYTES (8 * 1024 * 1024)
+#define PINN_STATIC_MAX_POINTS 65536
+int pinn_forward_vjp_static(pinn_handle *h, const float *theta, const float *x, const float *t,
+                            int64_t stride, int64_t n, const float *gbar, float *grad_theta_accum,
+                            void *stream);
+
 /* net_f: f_out[n][nf]; optional derivs_out[n][nout][J] = true derivatives
  * (d^k u/dx^k, k=0..K, then d/dt of orders 0..KT-1).  Replaces net_f's nested
  * torch.autograd.grad chain (:122-132).  Either output may be NULL. */
@@ -160,6 +176,7 @@ const char *pinn_error_string(int code);
 #define PINN_ERR_HIP (-3)
 #define PINN_ERR_NULL (-4)
 #define PINN_ERR_ALLOC (-5)
+#define PINN_ERR_TOO_LARGE (-6)
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,7 @@ _lib = None
 SYMBOLS = [
     "pinn_create", "pinn_destroy", "pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout",
     "pinn_kernel_kind", "pinn_forward", "pinn_forward_vjp", "pinn_residual_fwd", "pinn_residual_vjp",
-    "pinn_loss_grad", "pinn_error_string", "pinn_reserve",
+    "pinn_loss_grad", "pinn_error_string", "pinn_reserve", "pinn_forward_vjp_static",
     "pinn_lbfgs_workspace_floats", "pinn_lbfgs_direction", "pinn_lbfgs_eval_stats",
 ]
 
@@ -59,6 +59,7 @@ def load_library():
         getattr(lib, name).argtypes = [vp]
     lib.pinn_forward.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp]
     lib.pinn_forward_vjp.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
+    lib.pinn_forward_vjp_static.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_reserve.argtypes = [vp, i64]
     lib.pinn_residual_fwd.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_residual_vjp.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
@@ -160,6 +161,15 @@ class NativeEngine:
         with torch.cuda.device(self.device):
             _check(self.lib.pinn_forward_vjp(self._h, theta.data_ptr(), px, pt, stride, n, gbar.data_ptr(),
                                              grad_accum.data_ptr(), self._stream()), "pinn_forward_vjp")
+
+    def forward_vjp_static(self, theta, x, t, gbar, grad_accum):
+        """pinn_forward_vjp_static: same result, scratch in the library's static device array (no allocation)."""
+        self._chk_theta(theta)
+        kx, kt, px, pt, stride, n = _split_xt(x, t)
+        gbar = gbar.reshape(n, self.nout).contiguous().float()
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_forward_vjp_static(self._h, theta.data_ptr(), px, pt, stride, n, gbar.data_ptr(),
+                                                    grad_accum.data_ptr(), self._stream()), "pinn_forward_vjp_static")
 
     def reserve(self, n_max):
         """Size the handle's workspace for calls of up to n_max points: no later call allocates."""

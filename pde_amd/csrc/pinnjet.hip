@@ -1,5 +1,6 @@
 // C-ABI of the PINN collocation engine (include/pinnjet.h) and kernel dispatch.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <new>
 #include <stdlib.h>
 #include <string.h>
@@ -29,10 +30,33 @@ struct pinn_handle {
     int mfma_grid = 0;           // persistent grid of the MFMA kernels (<= n_cu)
 };
 
+// ---- the scratch of pinn_forward_vjp_static -------------------------------------------------------
+// Device memory that belongs to the code object, one copy per GPU the library runs on, held until the
+// process ends.  The NAME is a host-side stand-in: host code only ever uses the per-device address
+// that hipGetSymbolAddress returned (g_static_ptr), as kernel argument and as memset target.
+static __device__ __align__(256) unsigned char scratch[PINN_STATIC_SCRATCH_BYTES];
+
 namespace {
 
+constexpr int MAX_DEVICES = 64;
+void *g_static_ptr[MAX_DEVICES];      // per device: address of `scratch` on that device (0 = not looked up yet)
+std::mutex g_static_mu;
+
+// Look the static scratch array up on the CURRENT device (once per device).  Called from pinn_create,
+// i.e. at set-up, never from the no-allocation entry point's steady state.
+int static_scratch_lookup(int device)
+{
+    if (device < 0 || device >= MAX_DEVICES) return PINN_ERR_INVALID_DESC;
+    std::lock_guard<std::mutex> lk(g_static_mu);
+    if (g_static_ptr[device]) return PINN_OK;
+    void *ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) { (void)hipGetLastError(); return PINN_ERR_HIP; }
+    g_static_ptr[device] = ptr;
+    return PINN_OK;
+}
+
 // where a call's scratch memory comes from: the handle's own buffers (grown on demand) or a fixed
-// region that the grid is sized to fit
+// region (the static array) that the grid is sized to fit
 struct FixedWs {
     unsigned char *base;
     size_t bytes;
@@ -182,7 +206,7 @@ int run(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, float *
         // size the (persistent) grid to the fixed region; every kernel strides its tiles over whatever grid it gets
         const size_t per_wg = nd.jets_per_wg + nd.slab_per_wg;
         const long long fit = per_wg ? (long long)((fixed->bytes - 256) / per_wg) : grid;
-        if (fit < 1) return PINN_ERR_UNSUPPORTED;
+        if (fit < 1) return PINN_ERR_TOO_LARGE;
         if (fit < grid) grid = (int)fit;
         jets = (float *)fixed->base;
         slab = (float *)(fixed->base + align256(nd.jets_per_wg * grid));
@@ -286,6 +310,8 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     if (kernel == PINN_KERNEL_VALU && (size_t)(kd.P + 2) * sizeof(float) > 160 * 1024) { delete h; return PINN_ERR_UNSUPPORTED; }
     h->kernel = kernel;
     h->mfma_grid = h->n_cu;      // persistent kernels: at most one workgroup per CU
+    // set-up work of the no-allocation entry point: this device's address of the static scratch array
+    { const int rc = static_scratch_lookup(h->device); if (rc) { delete h; return rc; } }
     *out = h;
     return PINN_OK;
 }
@@ -319,6 +345,23 @@ int pinn_forward_vjp(pinn_handle *h, const float *theta, const float *x, const f
     if (!gbar || !grad_theta_accum) return PINN_ERR_NULL;
     CallArgs a{theta, x, t, stride, n, gbar, 0.0f, nullptr, nullptr, nullptr};
     return run(h, PINN_EQ_NONE, MODE_VJP, a, grad_theta_accum, nullptr, stream);
+}
+
+int pinn_forward_vjp_static(pinn_handle *h, const float *theta, const float *x, const float *t, int64_t stride,
+                            int64_t n, const float *gbar, float *grad_theta_accum, void *stream)
+{
+    if (!h) return PINN_ERR_NULL;
+    if (!gbar || !grad_theta_accum) return PINN_ERR_NULL;
+    if (n > PINN_STATIC_MAX_POINTS) return PINN_ERR_TOO_LARGE;
+    // the array lives on the handle's device, at the address looked up when the handle was created
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return PINN_ERR_HIP; }
+    if (cur != h->device) return PINN_ERR_INVALID_DESC;
+    void *ptr = g_static_ptr[h->device];
+    if (!ptr) return PINN_ERR_HIP;
+    const FixedWs ws{(unsigned char *)ptr, (size_t)PINN_STATIC_SCRATCH_BYTES};
+    CallArgs a{theta, x, t, stride, n, gbar, 0.0f, nullptr, nullptr, nullptr};
+    return run(h, PINN_EQ_NONE, MODE_VJP, a, grad_theta_accum, nullptr, stream, &ws);
 }
 
 int pinn_reserve(pinn_handle *h, int64_t n_max)
@@ -377,6 +420,7 @@ const char *pinn_error_string(int code)
     case PINN_ERR_HIP: return "HIP runtime error";
     case PINN_ERR_NULL: return "null pointer";
     case PINN_ERR_ALLOC: return "device allocation failed";
+    case PINN_ERR_TOO_LARGE: return "problem too large for the static scratch of the no-allocation entry point";
     default: return "unknown error";
     }
 }
