@@ -47,7 +47,7 @@ CASES = [
     ("kdv5_xavier", scripts.kdv5_1soliton.PI.PhysicsInformedNN, "pi"),
     ("burgers_9x20_xavier", scripts.burgers.PI.PhysicsInformedNN, "burgers"),
     ("ch_w64_xavier", scripts.camassa_holm.PI.PhysicsInformedNN, "pi"),
-    ("ch_bc_xavier", scripts.camassa_holm_bc.PI.PhysicsInformedNN, "pi"),
+    ("ch_bc_xavier", scripts.camassa_holm_bc.bc.PhysicsInformedNN, "pi"),
     ("gnss_w50_xavier", scripts.gnss.PI.PhysicsInformedNN, "gnss"),
     ("gnss_w100_ckpt", scripts.gnss.sw.PhysicsInformedNN, "gnss_sw"),
 ]
@@ -141,6 +141,52 @@ def test_adam_step_runs_and_decreases_loss():
     feed(m, g, "burgers")
     m.train(3, LBFGS_max_iter=0)
     assert m.iter == 3
+
+
+def test_script_literals_match_reference():
+    """pde_amd/scripts.py vs the literals oracle/gen_script_literals.py read out of the reference's
+    source text (tests/golden/script_literals.json): every class definition of every hot-path script
+    has a drop-in with the same residual body, IC time t0, boundary-loss form, Adam/AdamW choice and
+    L-BFGS settings (lr, max_eval, history_size, tolerance_grad) — e.g. 7kdv/sw-73.py:173-177,
+    CH/PI-CH-1soliton.py:147-151, 5kdv/PI-52.py:150, NLS/bc-GNSS-torch.py:102."""
+    import json
+    lit = json.load(open(os.path.join(GOLDEN, "script_literals.json")))
+    assert set(lit) == set(scripts.BY_SCRIPT), set(lit) ^ set(scripts.BY_SCRIPT)
+    n = 0
+    for path, ent in lit.items():
+        ns = scripts.for_script(path)
+        assert {c["class"] for c in ent["classes"]} == {k for k in vars(ns) if k.endswith("PhysicsInformedNN")}, path
+        for c in ent["classes"]:
+            v = getattr(ns, c["class"]).variant
+            where = "%s:%s" % (path, c["class"])
+            assert v.equation == c["equation"], where
+            assert v.bc == c["bc_form"], where
+            assert v.optimizer == c["optimizer"], where
+            if c["optimizer"] == "adamw":
+                assert v.weight_decay == c["weight_decay"], where
+            if c["t0"] == "argument":
+                assert v.style == "bc", where
+            else:
+                assert v.t0 == c["t0"], where
+            assert v.style == ("bc" if c["class"] == "bcPhysicsInformedNN" else
+                               "sw" if "X_prev=None" in c["set_training_data"] else "pi"), where
+            for k in ("lr", "max_eval", "history_size", "tolerance_grad"):
+                assert float(v.lbfgs[k]) == c["lbfgs"][k], (where, k)
+            n += 1
+    assert n == 40
+
+
+def test_train_hands_the_script_literals_to_lbfgs():
+    """train() builds its L-BFGS from the variant: CH/PI-CH-1soliton.py:147-151 (lr 0.5, max_eval 75000,
+    history 150, tolerance_grad 1e-7) and the reference's tolerance_change = np.finfo(float).eps."""
+    g = np.load(os.path.join(GOLDEN, "ch_ckpt.npz"))
+    m = make_model(g, scripts.for_script("CH/PI-CH-1soliton.py").PhysicsInformedNN)
+    feed(m, g, "pi")
+    type(m).lbfgs_impl = "torch"
+    m.train(0, LBFGS_max_iter=0)
+    grp = m.optimizer_LBFGS.param_groups[0]
+    assert (grp["lr"], grp["max_eval"], grp["history_size"], grp["tolerance_grad"]) == (0.5, 75000, 150, 1e-7)
+    assert grp["tolerance_change"] == np.finfo(float).eps and grp["line_search_fn"] == "strong_wolfe"
 
 
 @pytest.mark.skipif(not os.path.exists(LIB_PATH), reason="libpinnjet.so not built")
