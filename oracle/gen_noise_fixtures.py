@@ -1,0 +1,97 @@
+"""TEST INFRASTRUCTURE — NOT PRODUCT CODE.  Container-only (needs /root/reference).
+
+The fp32 noise floor of the REFERENCE at its shipped checkpoints, measured robustly.
+
+At trained weights the PDE residual is a ~1000x cancellation, so the reference's own fp32 run differs
+from its fp64 run by 1e-4..3e-3 (relative) — and on ONE small batch that number is luck: over 256-point
+batches the ratio between two equally good fp32 implementations swings between 0.2x and 8x.  A bar of
+the form "no worse than c x the reference's own fp32 error"  is therefore only
+meaningful on the RMS over many batches.  This script imports the reference's scripts (like
+gen_golden.py), evaluates `net_f`, `loss_f` and its gradient in fp32 and fp64 on NB batches of B
+uniform points per checkpoint, and stores per batch only what a test needs:
+
+  X [NB,B,2] f32 points, f64 [NB,B,nf] the reference's fp64 residual,
+  ref_f_err / ref_f_norm   [NB]  ||f32 - f64||, ||f64||
+  ref_g_err / ref_g_norm   [NB]  ||grad32 - grad64||, ||grad64||   (gradient of loss_f = sum_c mean f_c^2)
+  ref_loss32 / ref_loss64  [NB]
+
+tests compare the HIP path's errors against the fp64 C oracle (itself pinned to the reference's fp64
+to 1e-10, and cross-checked here against f64) with these reference noise levels.
+Run:  python oracle/gen_noise_fixtures.py
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gen_golden import OUT, REF, flat_grad, flat_theta, load_script, set_dtype  # noqa: E402
+
+NB, B = 12, 256
+L50 = [2, 50, 50, 50, 50, 1]
+CASES = [
+    # name, eq, script, class, layers, lb, ub, checkpoint
+    ("kdv7_3sol_ckpt", "kdv7_3sol", "7kdv/PI-7kdv3soliton.py", L50, [-15.0, -0.5], [15.0, 0.5], "7kdv/model/PI 73.pth"),
+    ("kdv7_1sol_ckpt", "kdv7_1sol", "7kdv/PI-7kdv1soliton.py", L50, [-10.0, -2.0], [10.0, 2.0], "7kdv/model/PI 1t-2.pth"),
+    ("kdv7_sw_ckpt", "kdv7_3sol", "7kdv/sw-73.py", L50, [-15.0, -0.5], [15.0, 0.0], "7kdv/model/sw73_1.pth"),
+    ("kdv5_ckpt", "kdv5", "5kdv/PI-51.py", L50, [-10.0, -2.0], [10.0, 2.0], "5kdv/model/PINN1t-2.pth"),
+    ("burgers_ckpt", "burgers", "Burgers/Burgers_equation(PINN).py", L50, [-1.0, 0.0], [1.0, 0.99],
+     "Burgers/model/model_50,50,10000,4x50.pth"),
+    ("ch_ckpt", "ch", "CH/PI-CH-1soliton.py", L50, [-15.0, -1.0], [15.0, 1.0], "CH/model/PINN CH.pth"),
+    ("gnss_w100_ckpt", "gnss", "NLS/sw-GNSS-adamW.py", [2, 100, 100, 100, 100, 2], [-5.0, -2.0], [5.0, 0.0],
+     "NLS/model/adamWsw(0.1+0)t-2_1.pth"),
+    ("gnss_w50_ckpt", "gnss", "NLS/PI-GNSS-torch.py", [2, 50, 50, 50, 50, 2], [-5.0, -2.0], [5.0, 2.0],
+     "NLS/model/PINN-(0.1+0)t-2.pth"),
+]
+
+
+def main():
+    torch.set_num_threads(8)
+    for name, eq, script, layers, lb, ub, ckpt in CASES:
+        mod = load_script(script)
+        lb, ub = np.array(lb), np.array(ub)
+        mod.lb, mod.ub = lb, ub
+        model = mod.PhysicsInformedNN(layers, lb, ub)
+        model.dnn.load_state_dict(torch.load(os.path.join(REF, ckpt), map_location="cpu", weights_only=True))
+        theta = flat_theta(model).astype(np.float32)
+        rng = np.random.default_rng(20260211)
+        X = (lb + (ub - lb) * rng.random((NB, B, 2))).astype(np.float32)
+        nf = 2 if eq == "gnss" else 1
+        rec = {k: np.zeros(NB) for k in ("ref_f_err", "ref_f_norm", "ref_g_err", "ref_g_norm", "ref_loss32", "ref_loss64")}
+        f64_all = np.zeros((NB, B, nf))
+        for b in range(NB):
+            res = {}
+            for tag, dtype in (("64", torch.float64), ("32", torch.float32)):
+                set_dtype(model, dtype)
+                if eq == "burgers":
+                    model.nu = torch.tensor(0.01 / np.pi).float().to(dtype)
+                x = torch.tensor(X[b, :, 0:1].astype(np.float64)).to(dtype).requires_grad_(True)
+                t = torch.tensor(X[b, :, 1:2].astype(np.float64)).to(dtype).requires_grad_(True)
+                for p in model.dnn.parameters():
+                    p.grad = None
+                f = model.net_f(x, t)
+                fs = list(f) if isinstance(f, tuple) else [f]
+                loss = sum(torch.mean(torch.square(fi)) for fi in fs)
+                loss.backward()
+                res[tag] = (np.concatenate([fi.detach().numpy() for fi in fs], axis=1).astype(np.float64),
+                            float(loss.item()), flat_grad(model).astype(np.float64))
+            f64, l64, g64 = res["64"]
+            f32, l32, g32 = res["32"]
+            f64_all[b] = f64
+            rec["ref_f_err"][b] = np.linalg.norm(f32 - f64)
+            rec["ref_f_norm"][b] = np.linalg.norm(f64)
+            rec["ref_g_err"][b] = np.linalg.norm(g32 - g64)
+            rec["ref_g_norm"][b] = np.linalg.norm(g64)
+            rec["ref_loss32"][b], rec["ref_loss64"][b] = l32, l64
+        np.savez_compressed(os.path.join(OUT, "noise_" + name + ".npz"), theta=theta, X=X, f64=f64_all,
+                            eq=np.array(eq), layers=np.array(layers), lb=lb, ub=ub,
+                            source=np.array("%s + %s, %d batches of %d uniform points" % (script, ckpt, NB, B)), **rec)
+        rf = np.sqrt(np.mean((rec["ref_f_err"] / rec["ref_f_norm"]) ** 2))
+        rg = np.sqrt(np.mean((rec["ref_g_err"] / rec["ref_g_norm"]) ** 2))
+        print("wrote noise_%s: reference fp32 noise rms over batches  f %.2e  grad %.2e" % (name, rf, rg))
+
+
+if __name__ == "__main__":
+    main()

@@ -24,27 +24,47 @@ template <> struct EqTraits<EQ_GNSS>    { static constexpr int K = 3, KT = 1; };
 
 constexpr int MAXOUT = 2;
 
-__device__ __forceinline__ float fast_tanh(float x)
+// tanh(x) and w0 = 1 - tanh(x)^2 = sech(x)^2, both to ~1 ulp, branch-free.
+//
+// Why not exp-based (1 - e)/(1 + e) with the hardware v_exp_f32 (what round 1 shipped): e carries >= 1 ulp
+// of ABSOLUTE error near 1, which 1 - e turns into several ulp of tanh for |x| in [0.04, 0.3], and
+// w0 = 1 - y^2 then inherits 2|y| ulp(1) of absolute error however small w0 is.  At trained weights the
+// PDE residual is a ~1000x cancellation of terms that are all linear in these two numbers, and the extra
+// ulps showed up as 2-3x the residual / gradient noise of the reference's own fp32 run
+// (oracle variants: a +2 ulp bias in tanh alone gives 2-8x).
+//
+// Here: a = -2|x| = n ln2 + r, |r| <= ln2/2;  p = expm1(r) by its Taylor polynomial through r^8/8!
+// (relative error < 0.3 ulp, r is exact for n = 0);  e = exp(a) = s (1 + p), s = 2^n.  Then
+//     1 - e = (1 - s) - s p     (exact for n = 0: no cancellation error at all),
+//     1 + e = (1 + s) + s p,    tanh = (1 - e)/(1 + e),    sech^2 = 4 e / (1 + e)^2,
+// with one Newton step on the reciprocal and one on the quotient.  28 VALU instructions (one
+// transcendental), 7 more than the version it replaces.  Accuracy on the GPU: tools/ubench/tanh_accuracy.hip.
+__device__ __forceinline__ float tanh_sech2(float x, float &w0)
 {
-    // Branch-free tanh(x) = sign(x) (1 - e)/(1 + e), e = exp(-2|x|), to ~1-2 ulp:
-    //  * the exponent -2|x| log2(e) is formed as hi + lo (fma residual + low word of the constant) so
-    //    that v_exp_f32's argument rounding does not cost |x| ulps;
-    //  * the quotient gets one Newton step on top of v_rcp_f32;
-    //  * for |x| < 0.04 the odd series avoids the cancellation in 1 - e.
     const float ax = fabsf(x);
-    const float c_hi = -2.885390043258667f, c_lo = -3.851960541e-8f;   // -2/ln2 = c_hi + c_lo
-    const float hi = ax * c_hi;
-    const float lo = fmaf(ax, c_hi, -hi) + ax * c_lo;
-    float e = __builtin_amdgcn_exp2f(hi);
-    e = fmaf(e, lo * 0.6931471806f, e);
-    const float num = 1.0f - e, den = 1.0f + e;
-    const float rc = __builtin_amdgcn_rcpf(den);
-    float r = num * rc;
-    r = fmaf(fmaf(-den, r, num), rc, r);
-    const float x2 = x * x;
-    const float s = ax * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.05396825f * x2)));
-    r = ax < 0.04f ? s : r;
-    return copysignf(r, x);
+    const float a = -2.0f * ax;
+    float nf = __builtin_rintf(a * 1.44269504f);
+    nf = fmaxf(nf, -64.0f);                       // |x| > 22: e = 2^-64 (1 + p), tanh = 1 and sech^2 ~ 0 in float
+    float r = fmaf(nf, -0.693145752f, a);         // ln2 = hi + lo, hi with 9 trailing zero bits: n * hi is exact
+    r = fmaf(nf, -1.42860677e-6f, r);
+    float q = 1.0f / 40320.0f;
+    q = fmaf(q, r, 1.0f / 5040.0f);
+    q = fmaf(q, r, 1.0f / 720.0f);
+    q = fmaf(q, r, 1.0f / 120.0f);
+    q = fmaf(q, r, 1.0f / 24.0f);
+    q = fmaf(q, r, 1.0f / 6.0f);
+    q = fmaf(q, r, 0.5f);
+    const float p = fmaf(r * r, q, r);            // expm1(r)
+    const float s = __builtin_amdgcn_ldexpf(1.0f, (int)nf);
+    const float e4 = fmaf(4.0f * s, p, 4.0f * s); // 4 e
+    const float num = fmaf(-s, p, 1.0f - s);
+    const float den = fmaf(s, p, 1.0f + s);
+    float rc = __builtin_amdgcn_rcpf(den);
+    rc = fmaf(fmaf(-den, rc, 1.0f), rc, rc);
+    float y = num * rc;
+    y = fmaf(fmaf(-den, y, num), rc, y);
+    w0 = (e4 * rc) * rc;
+    return copysignf(y, x);
 }
 
 // ---- tanh on a jet -----------------------------------------------------------
@@ -74,8 +94,7 @@ __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float
 {
     constexpr int KW0 = KT - 1 > K - 1 ? KT - 1 : K - 1;
     constexpr int KW = KW0 < K ? KW0 : K;   // highest w order anything reads: y_k uses w_0..w_{k-1}, t-tangents w_0..w_{KT-1}
-    y[0] = fast_tanh(z[0]);   // branch-free: keeps a whole tile's tanh work in one scheduling region
-    w[0] = fmaf(-y[0], y[0], 1.0f);
+    y[0] = tanh_sech2(z[0], w[0]);   // branch-free: keeps a whole tile's tanh work in one scheduling region
     float zs[K + 1], ym2[K / 2 + 1];
 #pragma unroll
     for (int j = 1; j <= ZN; ++j) zs[j] = (float)j * z[j];
@@ -97,18 +116,6 @@ __device__ __forceinline__ void tanh_jet_fwd(const float (&z)[K + 1 + KT], float
         for (int j = (k - ZTN + 1 > 0 ? k - ZTN + 1 : 0); j <= k; ++j) s = fmaf(w[j], z[K + 1 + k - j], s);
         y[K + 1 + k] = s;
     }
-}
-
-// w jets from y alone (used by the reverse sweep, which re-reads y instead of w)
-template <int K>
-__device__ __forceinline__ void w_from_y(const float *y, float (&w)[K + 1])
-{
-    float ym2[K / 2 + 1];
-#pragma unroll
-    for (int k = 0; k <= K / 2; ++k) ym2[k] = -2.0f * y[k];
-    w[0] = fmaf(-y[0], y[0], 1.0f);
-#pragma unroll
-    for (int k = 1; k <= K; ++k) w_order<K, 0>(y, ym2, k, w[k]);
 }
 
 // reverse of tanh_jet_fwd: yb (adjoint of y, modified in place) -> zb.  With ZN < K / ZTN < KT the adjoints

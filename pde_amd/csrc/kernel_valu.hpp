@@ -231,13 +231,12 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
                 for (int ib = 0; ib < VALU_OB; ++ib) {
                     if (i0 + ib < nin) {
                         const int i = i0 + ib;
+                        // y and w = sech^2 jets are recomputed from the stashed z (w0 comes out of tanh_sech2
+                        // directly; re-forming it as 1 - y0^2 from the stashed y would lose its accuracy)
                         float z[J], y[J], w[K + 1], zbn[J];
 #pragma unroll
-                        for (int j = 0; j < J; ++j) {
-                            z[j] = SL(sl.z[l - 1] + i * J + j);
-                            y[j] = SL(sl.y[l - 1] + i * J + j);
-                        }
-                        w_from_y<K>(y, w);
+                        for (int j = 0; j < J; ++j) z[j] = SL(sl.z[l - 1] + i * J + j);
+                        tanh_jet_fwd<K, KT>(z, y, w);
                         tanh_jet_bwd<K, KT>(z, y, w, ab[ib], zbn);
 #pragma unroll
                         for (int j = 0; j < J; ++j) SL(nxt + i * J + j) = zbn[j];

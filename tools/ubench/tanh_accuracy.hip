@@ -1,0 +1,57 @@
+// Accuracy of tanh_sech2 (pde_amd/csrc/jet_math.hpp) on the GPU against double precision, in ulps of the
+// exact value, over every float in a set of |x| ranges (stride 1 below 2^22 values per range).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize tools/ubench/tanh_accuracy.hip -o tools/ubench/tanh_accuracy
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../pde_amd/csrc/jet_math.hpp"
+
+struct Stat { double max_y, sum2_y, max_w, sum2_w; unsigned long long n; };
+
+__device__ double ulp_of(double exact)
+{
+    int ex;
+    frexp(fabs(exact), &ex);                 // |exact| = m 2^ex, m in [0.5, 1)
+    return ldexp(1.0, ex - 24);
+}
+
+__global__ void k_eval(unsigned int lo_bits, unsigned int count, unsigned int stride, double *part)
+{
+    double my = 0, sy = 0, mw = 0, sw = 0;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float x = __uint_as_float(lo_bits + i * stride);
+        float w0;
+        const float y = pinn::tanh_sech2((i & 1) ? -x : x, w0);
+        const double yd = tanh((double)x);
+        const double wd = 1.0 / (cosh((double)x) * cosh((double)x));
+        const double ey = fabs(fabs((double)y) - yd) / ulp_of(yd);
+        const double ew = wd > 1e-37 ? fabs((double)w0 - wd) / ulp_of(wd) : 0.0;
+        my = fmax(my, ey); sy += ey * ey; mw = fmax(mw, ew); sw += ew * ew;
+    }
+    double *o = part + 4 * (size_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    o[0] = my; o[1] = sy; o[2] = mw; o[3] = sw;
+}
+
+int main()
+{
+    const float edges[] = {1e-6f, 1e-3f, 0.04f, 0.17f, 0.35f, 0.7f, 1.5f, 3.0f, 6.0f, 10.0f, 20.0f};
+    const int nt = 256 * 1024;
+    double *dpart, *hpart = (double *)malloc(sizeof(double) * 4 * nt);
+    hipMalloc((void **)&dpart, sizeof(double) * 4 * nt);
+    printf("%-22s %10s %10s %10s %10s %12s\n", "|x| range", "max ulp y", "rms ulp y", "max ulp w0", "rms ulp w0", "samples");
+    for (int k = 0; k + 1 < (int)(sizeof(edges) / sizeof(edges[0])); ++k) {
+        unsigned int lo, hi;
+        memcpy(&lo, &edges[k], 4); memcpy(&hi, &edges[k + 1], 4);
+        const unsigned int span = hi - lo;
+        const unsigned int stride = span > (1u << 22) ? span >> 22 : 1;
+        const unsigned int count = span / stride;
+        hipMemset(dpart, 0, sizeof(double) * 4 * nt);
+        hipLaunchKernelGGL(k_eval, dim3(nt / 256), dim3(256), 0, 0, lo, count, stride, dpart);
+        hipMemcpy(hpart, dpart, sizeof(double) * 4 * nt, hipMemcpyDeviceToHost);
+        double my = 0, sy = 0, mw = 0, sw = 0;
+        for (int i = 0; i < nt; ++i) { my = fmax(my, hpart[4 * i]); sy += hpart[4 * i + 1]; mw = fmax(mw, hpart[4 * i + 2]); sw += hpart[4 * i + 3]; }
+        printf("[%9.3g, %9.3g) %10.3f %10.3f %10.3f %10.3f %12u\n", edges[k], edges[k + 1], my, sqrt(sy / count), mw, sqrt(sw / count), count);
+    }
+    return 0;
+}
