@@ -129,6 +129,13 @@ int pinn_forward_vjp_static(pinn_handle *h, const float *theta, const float *x, 
 int pinn_residual_fwd(pinn_handle *h, const float *theta, const float *x, const float *t,
                       int64_t stride, int64_t n, float *f_out, float *derivs_out, void *stream);
 
+/* The residual polynomial alone — the `return u_t + ...` line of net_f (7kdv/PI-7kdv3soliton.py:132,
+ * 5kdv/PI-51.py:140, Burgers/Burgers_equation(PINN).py:131, CH/PI-CH-1soliton.py:138,
+ * NLS/sw-GNSS-adamW.py:178-179) — on caller-supplied true derivatives derivs[n][nout][J] (layout of
+ * derivs_out): f_out[n][nf].  The same device code (Residual<EQ>) the fused kernels inline; it lets a
+ * caller check the formulas and coefficient sets on exact solutions, without any network. */
+int pinn_residual_from_derivs(pinn_handle *h, const float *derivs, int64_t n, float *f_out, void *stream);
+
 /* theta-gradient of sum_p sum_c gbar[p][c] * f_c(x_p,t_p): what autograd's
  * backward through net_f's graph produces for an arbitrary loss on f. */
 int pinn_residual_vjp(pinn_handle *h, const float *theta, const float *x, const float *t,

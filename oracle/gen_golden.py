@@ -271,7 +271,36 @@ def main():
                   eval_case(mgp, "PhysicsInformedNN", L502, lb, ub, None, 1234, "gnss", 3, 1, pts, ex),
                   "NLS/PI-GNSS-torch.py + xavier(manual_seed 1234)"))
 
+    # ---- two-output bc class (loss1 over u1 AND v1), NLS/bc-GNSS-torch.py:222-312 ------------------
+    mgbc = load_script("NLS/bc-GNSS-torch.py")
+    lb, ub = np.array([-5.0, -1.0]), np.array([5.0, 1.0])
+    pts = sample_points(lb, ub, N_PTS, rng)
+    ex = data_terms(rng, lb, ub, -1.0, 2)
+    Xh = sample_points(lb, ub, 40, rng)
+    ex["x1"], ex["t1"] = Xh[:, 0:1], Xh[:, 1:2]
+    ex["u1"] = (0.8 * np.cos(Xh[:, 0:1]) / np.cosh(Xh[:, 1:2])).astype(np.float32)
+    ex["v1"] = (0.4 * np.sin(Xh[:, 0:1] + Xh[:, 1:2])).astype(np.float32)
+    cases.append(("gnss_bc_xavier", "gnss", L502, lb, ub,
+                  eval_case(mgbc, "bcPhysicsInformedNN", L502, lb, ub, None, 2468, "gnss", 3, 1, pts, ex),
+                  "NLS/bc-GNSS-torch.py bcPhysicsInformedNN (two outputs, loss1 on u1 and v1) + xavier(manual_seed 2468)"))
+
+    # ---- plain NLS (the GNSS body with c = 0), NLS/sw-PINN-rogue.py:160-181 ---------------------------
+    mnls = load_script("NLS/sw-PINN-rogue.py")
+    lb, ub = np.array([-5.0, -1.0]), np.array([5.0, 0.0])
+    pts = sample_points(lb, ub, N_PTS, rng)
+    ex = data_terms(rng, lb, ub, -1.0, 2)
+    Xp = sample_points(lb, ub, 20, rng)
+    ex["X_prev"] = Xp
+    ex["u_prev"] = (0.6 * np.cos(Xp[:, 0:1])).astype(np.float32)
+    ex["v_prev"] = (0.2 * np.sin(Xp[:, 1:2])).astype(np.float32)
+    cases.append(("nls_w100_xavier", "nls", L100, lb, ub,
+                  eval_case(mnls, "PhysicsInformedNN", L100, lb, ub, None, 1357, "gnss", 3, 1, pts, ex),
+                  "NLS/sw-PINN-rogue.py + xavier(manual_seed 1357)"))
+
+    only = os.environ.get("GEN_GOLDEN_ONLY")          # e.g. "gnss_bc_xavier,nls_w100_xavier": write just these
     for name, eq, layers, lb, ub, arrs, src in cases:
+        if only and name not in only.split(","):
+            continue
         arrs.update(eq=np.array(eq), layers=np.array(layers), lb=lb.astype(np.float64),
                     ub=ub.astype(np.float64), source=np.array(src))
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrs)

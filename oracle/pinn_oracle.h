@@ -34,4 +34,8 @@ int orc_loss_grad_f32(const orc_desc *d, const float *theta, const float *x, con
                       long n, const float *gbar, double scale, double *loss_sums, float *grad);
 int orc_loss_grad_f64(const orc_desc *d, const double *theta, const double *x, const double *t,
                       long n, const double *gbar, double scale, double *loss_sums, double *grad);
+/* the residual polynomial alone, on caller-supplied true derivatives derivs[n][nout][J]
+ * (layout of derivs_out): f_out[n][nf].  Used by the net-free known-answer tests. */
+int orc_residual_derivs_f32(const orc_desc *d, const float *derivs, long n, float *f_out);
+int orc_residual_derivs_f64(const orc_desc *d, const double *derivs, long n, double *f_out);
 #endif

@@ -343,6 +343,23 @@ int SFX(orc_forward)(const orc_desc *d, const REAL *theta, const REAL *x, const 
     return 0;
 }
 
+int SFX(orc_residual_derivs)(const orc_desc *d, const REAL *derivs, long n, REAL *f_out)
+{
+    int K, KT, nf;
+    if (orc_orders(d, &K, &KT, &nf)) return -1;
+    const int J = K + 1 + KT, nout = d->widths[d->n_lin];
+    for (long p = 0; p < n; ++p) {
+        REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXOUT];
+        for (int o = 0; o < nout; ++o) {
+            for (int k = 0; k <= K; ++k) D[o][k] = derivs[((size_t)p * nout + o) * J + k];
+            for (int k = 0; k < KT; ++k) T[o][k] = derivs[((size_t)p * nout + o) * J + K + 1 + k];
+        }
+        SFX(residual)(d, K, KT, D, T, f, NULL, NULL, NULL);
+        for (int c = 0; c < nf; ++c) f_out[(size_t)p * nf + c] = f[c];
+    }
+    return 0;
+}
+
 /* gbar == NULL: loss mode, cotangent of f_c is 2*scale*f_c and
  *               loss_sums[c] += sum_p f_c^2 (unscaled).
  * gbar != NULL: vjp mode, cotangent given [n][nf].

@@ -116,6 +116,16 @@ class Oracle:
         assert rc == 0, rc
         return der, f
 
+    def residual_from_derivs(self, derivs, dtype=np.float64):
+        """the residual polynomial alone on true derivatives [n, nout, J] -> f [n, nf]"""
+        derivs = np.ascontiguousarray(np.asarray(derivs, dtype=dtype).reshape(-1, self.nout, self.J))
+        n = derivs.shape[0]
+        f = np.zeros((n, self.nf), dtype=dtype)
+        fn = lib().orc_residual_derivs_f64 if dtype == np.float64 else lib().orc_residual_derivs_f32
+        rc = fn(ctypes.byref(self.desc), self._p(derivs), ctypes.c_long(n), self._p(f))
+        assert rc == 0, rc
+        return f
+
     def loss_grad(self, theta, x, t, scale=1.0, gbar=None, dtype=np.float64):
         """-> (loss_sums [nf] = sum_p f_c^2 (zeros in vjp mode), grad [P]).
         loss mode: grad = d/dtheta scale * sum_c sum_p f_c^2.

@@ -37,7 +37,7 @@ _lib = None
 SYMBOLS = [
     "pinn_create", "pinn_destroy", "pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout",
     "pinn_kernel_kind", "pinn_forward", "pinn_forward_vjp", "pinn_residual_fwd", "pinn_residual_vjp",
-    "pinn_loss_grad", "pinn_error_string", "pinn_reserve", "pinn_forward_vjp_static",
+    "pinn_loss_grad", "pinn_error_string", "pinn_reserve", "pinn_forward_vjp_static", "pinn_residual_from_derivs",
     "pinn_lbfgs_workspace_floats", "pinn_lbfgs_direction", "pinn_lbfgs_eval_stats",
 ]
 
@@ -61,6 +61,7 @@ def load_library():
     lib.pinn_forward_vjp.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_forward_vjp_static.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_reserve.argtypes = [vp, i64]
+    lib.pinn_residual_from_derivs.argtypes = [vp, vp, i64, vp, vp]
     lib.pinn_residual_fwd.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_residual_vjp.argtypes = [vp, vp, vp, vp, i64, i64, vp, vp, vp]
     lib.pinn_loss_grad.argtypes = [vp, vp, vp, vp, i64, i64, f32, vp, vp, vp]
@@ -187,6 +188,16 @@ class NativeEngine:
                                               der.data_ptr() if want_derivs else None, self._stream()),
                    "pinn_residual_fwd")
         return (f, der) if want_derivs else f
+
+    def residual_from_derivs(self, derivs):
+        """the residual polynomial alone on true derivatives (n, nout, J) -> f (n, nf)"""
+        derivs = derivs.reshape(-1, self.nout, self.J).contiguous().float()
+        n = derivs.shape[0]
+        f = torch.empty((n, self.nf), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.pinn_residual_from_derivs(self._h, derivs.data_ptr(), n, f.data_ptr(), self._stream()),
+                   "pinn_residual_from_derivs")
+        return f
 
     def residual_vjp(self, theta, x, t, gbar, grad_accum):
         self._chk_theta(theta)

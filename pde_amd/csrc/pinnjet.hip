@@ -124,6 +124,34 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *slab, int nbl
     }
 }
 
+// the residual polynomial alone (Residual<EQ>::eval, the `return u_t + ...` line of net_f) on
+// caller-supplied true derivatives [n][nout][J]: one point per thread
+template <int EQ>
+__global__ __launch_bounds__(256) void k_residual_from_derivs(KDesc d, const float *derivs, long long n, float *f_out)
+{
+    constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
+    const int nout = d.nout;
+    const int nf = (EQ == EQ_NONE) ? nout : (EQ == EQ_GNSS ? 2 : 1);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        float D[MAXOUT][J], T[MAXOUT][J], f[MAXOUT] = {0.0f, 0.0f};
+#pragma unroll
+        for (int o = 0; o < MAXOUT; ++o)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float v = (o < nout) ? derivs[(p * nout + o) * J + j] : 0.0f;
+                if (j <= K) { D[o][j] = v; T[o][j] = 0.0f; }
+                else { T[o][j - K - 1] = v; }
+            }
+#pragma unroll
+        for (int o = 0; o < MAXOUT; ++o)
+#pragma unroll
+            for (int j = KT; j < J; ++j) T[o][j] = 0.0f;
+        Residual<EQ>::eval(D, T, d.coef, nout, f);
+        for (int c = 0; c < nf; ++c) f_out[p * nf + c] = f[c];
+    }
+}
+
 template <int EQ, int MODE>
 int launch_valu_t(float *jets, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
@@ -391,6 +419,27 @@ int pinn_residual_fwd(pinn_handle *h, const float *theta, const float *x, const 
     if (!f_out && !derivs_out) return PINN_ERR_NULL;
     CallArgs a{theta, x, t, stride, n, nullptr, 0.0f, f_out, derivs_out, nullptr};
     return run(h, h->desc.eq, MODE_FWD, a, nullptr, nullptr, stream);
+}
+
+int pinn_residual_from_derivs(pinn_handle *h, const float *derivs, int64_t n, float *f_out, void *stream)
+{
+    if (!h) return PINN_ERR_NULL;
+    if (!derivs || !f_out) return PINN_ERR_NULL;
+    if (n < 0) return PINN_ERR_INVALID_DESC;
+    if (n == 0) return PINN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long nb = (n + 255) / 256;
+    const dim3 grid((unsigned)(nb < 4096 ? nb : 4096)), block(256);
+    switch (h->desc.eq) {
+    case PINN_EQ_NONE:    hipLaunchKernelGGL(k_residual_from_derivs<EQ_NONE>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    case PINN_EQ_BURGERS: hipLaunchKernelGGL(k_residual_from_derivs<EQ_BURGERS>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    case PINN_EQ_KDV5:    hipLaunchKernelGGL(k_residual_from_derivs<EQ_KDV5>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    case PINN_EQ_KDV7:    hipLaunchKernelGGL(k_residual_from_derivs<EQ_KDV7>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    case PINN_EQ_CH:      hipLaunchKernelGGL(k_residual_from_derivs<EQ_CH>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    case PINN_EQ_GNSS:    hipLaunchKernelGGL(k_residual_from_derivs<EQ_GNSS>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    default: return PINN_ERR_INVALID_DESC;
+    }
+    return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 
 int pinn_residual_vjp(pinn_handle *h, const float *theta, const float *x, const float *t, int64_t stride,

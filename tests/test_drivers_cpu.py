@@ -136,3 +136,139 @@ def test_lhs_device_and_tensor_collocation_points():
     b.set_training_data(x0, np.exp(-x0 ** 2), tb, Xf.numpy())
     assert a.xf.dtype == torch.float32 and torch.equal(a.xf, b.xf) and torch.equal(a.tf, b.tf)
     assert a.n_f_global == 50
+
+
+# ---- end-to-end pins produced by the reference itself (oracle/gen_driver_fixtures.py) ---------------------
+from collections import OrderedDict  # noqa: E402
+import re  # noqa: E402
+
+import torch  # noqa: E402
+
+from conftest import GOLDEN  # noqa: E402
+
+
+def write_state_dict(path, theta, layers):
+    """theta (flat, state-dict order) -> a .pth with the reference's keys 1.layers.layer_i.{weight,bias}"""
+    sd, off = OrderedDict(), 0
+    for i in range(len(layers) - 1):
+        fi, fo = layers[i], layers[i + 1]
+        sd["1.layers.layer_%d.weight" % i] = torch.tensor(theta[off:off + fi * fo].reshape(fo, fi).copy())
+        off += fi * fo
+        sd["1.layers.layer_%d.bias" % i] = torch.tensor(theta[off:off + fo].copy())
+        off += fo
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save(sd, path)
+
+
+def run_sw73_test_mode(cls, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "predict_sw73.npz"))
+    for w in range(3):
+        write_state_dict(os.path.join(str(tmp_path), "model", "sw73_%d.pth" % (w + 1)), g["thetas"][w], g["layers"].tolist())
+    cls = type("SW73", (cls,), {"base_dir": str(tmp_path)})
+    models, full, err = drivers.sliding_window(cls, g["layers"].tolist(), g["x"], g["t"], g["uu"], train=False,
+                                               model_name="sw73_{win}.pth")
+    # the windows the driver derived are the reference's (7kdv/sw-73.py:250-252,268-273)
+    for m, b in zip(models, g["bounds"]):
+        assert np.allclose(np.concatenate([m._lb64, m._ub64]), b, atol=1e-12)
+    return g, full, err
+
+
+def test_sliding_window_test_mode_reproduces_error_txt(tmp_path):
+    """7kdv/sw-73.py in test mode (:343-376) with the shipped sw73_{1,2,3}.pth: error.txt:109-110 records
+    'Overall Error u: 3.223475e-02'; the reference run in the build container gives 3.223474e-02."""
+    g, full, err = run_sw73_test_mode(install(scripts.for_script("7kdv/sw-73.py").PhysicsInformedNN), tmp_path)
+    assert abs(err - float(g["err_ref"])) < 1e-6 * float(g["err_ref"])
+    assert abs(err - 3.223475e-02) < 5e-8
+    assert np.max(np.abs(full[g["sel"], 0] - g["u_full_sel"])) < 2e-5 * np.max(np.abs(g["u_full_sel"]))
+
+
+def test_predict_known_answer_kdv5_error_txt():
+    """5kdv/PI-51.py:262-267 with 5kdv/model/PINN1t-2.pth: error.txt:4, 'Error u: 2.446954e-02'."""
+    g = np.load(os.path.join(GOLDEN, "predict_kdv5.npz"))
+    m = install(scripts.for_script("5kdv/PI-51.py").PhysicsInformedNN)(g["layers"].tolist(), g["lb"], g["ub"])
+    from test_host_logic import load_theta
+    load_theta(m, g["theta"])
+    u = m.predict(drivers.grid_points(g["x"], g["t"]))
+    err = drivers.relative_l2(u, g["uu"].flatten()[:, None])
+    assert abs(err - 2.446954e-02) < 5e-8 and abs(err - float(g["err_ref"])) < 1e-6 * err
+
+
+def test_load_model_reads_a_checkpoint_the_reference_wrote(tmp_path):
+    """tests/golden/ref_written_kdv7.pth was written by the reference's own save_model()
+    (7kdv/PI-7kdv3soliton.py:173-177): load_model() takes it as is (weights_only load), bit for bit."""
+    import shutil
+    g = np.load(os.path.join(GOLDEN, "ref_written_kdv7.npz"))
+    os.makedirs(os.path.join(str(tmp_path), "model"))
+    shutil.copy(os.path.join(GOLDEN, "ref_written_kdv7.pth"), os.path.join(str(tmp_path), "model", "w.pth"))
+    cls = type("M", (install(scripts.for_script("7kdv/PI-7kdv3soliton.py").PhysicsInformedNN),), {"base_dir": str(tmp_path)})
+    m = cls(g["layers"].tolist(), g["lb"], g["ub"])
+    assert list(m.dnn.state_dict().keys()) == [str(k) for k in g["keys"]]
+    m.load_model("w.pth")
+    assert np.array_equal(m.dnn.flat_theta().numpy(), g["theta"])
+    assert np.max(np.abs(m.predict(g["X"]) - g["u"])) < 1e-5 * np.max(np.abs(g["u"]))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/7kdv"), reason="the reference tree only exists in the build container")
+def test_reference_loads_a_checkpoint_we_wrote(tmp_path):
+    """The other direction of the .pth interchange: the reference's own load_model() reads what our
+    save_model() wrote (container-only: needs the reference importable)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "oracle"))
+    from gen_golden import load_script
+    g = np.load(os.path.join(GOLDEN, "ref_written_kdv7.npz"))
+    cls = type("M", (install(scripts.for_script("7kdv/PI-7kdv3soliton.py").PhysicsInformedNN),), {"base_dir": str(tmp_path)})
+    torch.manual_seed(3)
+    m = cls(g["layers"].tolist(), g["lb"], g["ub"])
+    m.save_model("ours.pth")
+    mod = load_script("7kdv/PI-7kdv3soliton.py")
+    mod.current_dir = str(tmp_path)
+    mod.lb, mod.ub = g["lb"], g["ub"]
+    ref = mod.PhysicsInformedNN(g["layers"].tolist(), g["lb"], g["ub"])
+    ref.load_model("ours.pth")
+    got = torch.cat([p.detach().reshape(-1) for p in ref.dnn.parameters()]).numpy()
+    assert np.array_equal(got, m.dnn.flat_theta().numpy())
+    assert np.max(np.abs(ref.predict(g["X"]) - m.predict(g["X"]))) < 1e-5
+
+
+LOG_KEYS = {"pi": ["Iter", "Loss", "Loss_0", "Loss_b", "Loss_f"],
+            "sw": ["Iter", "Loss", "Loss0", "Loss_b", "Loss_f", "Loss_prev"],
+            "bc": ["Iter", "Loss", "Loss_0", "Loss_1", "Loss_b", "Loss_f"]}
+
+
+def parse_log_line(line):
+    items = [kv.split(": ") for kv in line.split(", ")]
+    return [k for k, _ in items], [float(v) for _, v in items]
+
+
+@pytest.mark.parametrize("tag,script,cname", [("pi", "7kdv/PI-7kdv3soliton.py", "PhysicsInformedNN"),
+                                              ("sw", "7kdv/sw-73.py", "PhysicsInformedNN"),
+                                              ("bc", "7kdv/bc-7kdv3soliton.py", "bcPhysicsInformedNN")])
+def test_log_file_matches_what_the_reference_wrote(tag, script, cname, tmp_path):
+    """train(1, logfile, 0, 1) on the weights and data of tests/golden/ref_logs.npz writes the log file the
+    reference wrote: 'Start Training:', the Iter-0 line with the same keys in the same order and %.5e values
+    (agreeing to 1e-4: fp32 kernels vs the reference's fp32 autograd), 'Training time: %.4f'.  The format
+    of a long run is the shipped 7kdv/log/log-PI 73.txt:1-3."""
+    from test_host_logic import load_theta
+    g = np.load(os.path.join(GOLDEN, "ref_logs.npz"))
+    cls = type("M", (install(getattr(scripts.for_script(script), cname)),), {"base_dir": str(tmp_path), "lbfgs_impl": "torch"})
+    m = cls(g["layers"].tolist(), g["lb"], g["ub"])
+    load_theta(m, g["theta_" + tag])
+    if tag == "pi":
+        m.set_training_data(g["x0"], g["u0"], g["tb"], g["Xf"])
+    elif tag == "sw":
+        m.set_training_data(g["x0"], g["u0"], g["tb"], g["Xf"], g["X_prev"], g["u_prev"])
+    else:
+        m.set_training_data(g["x0"], g["u0"], -0.5, g["u1"], g["tb"], g["Xf"], g["Xh"])
+    m.train(1, "ours.txt", 0, 1)
+    ours = open(os.path.join(str(tmp_path), "log", "ours.txt"), encoding="utf-8").read().split("\n")
+    ref = str(g["log_" + tag]).split("\n")
+    assert len(ours) == len(ref) == 4 and ours[0] == ref[0] == "Start Training:" and ours[3] == ref[3] == ""
+    keys_o, vals_o = parse_log_line(ours[1])
+    keys_r, vals_r = parse_log_line(ref[1])
+    assert keys_o == keys_r == LOG_KEYS[tag]
+    assert re.fullmatch(r"Iter: \d+(, \w+: \d\.\d{5}e[+-]\d\d)+", ours[1]) and re.fullmatch(r"Iter: \d+(, \w+: \d\.\d{5}e[+-]\d\d)+", ref[1])
+    assert np.allclose(vals_o, vals_r, rtol=1e-4)
+    assert re.fullmatch(r"Training time: \d+\.\d{4}", ours[2]) and re.fullmatch(r"Training time: \d+\.\d{4}", ref[2])
+    if tag == "pi":   # a shipped log of a long run has exactly this shape
+        head = str(g["shipped_log_head"]).split("\n")
+        assert head[0] == "Start Training:" and parse_log_line(head[1])[0] == LOG_KEYS["pi"] and parse_log_line(head[2])[1][0] == 100

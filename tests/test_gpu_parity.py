@@ -324,6 +324,8 @@ def _load_theta(model, theta):
     ("burgers_ckpt", scripts.burgers.PI.PhysicsInformedNN, "burgers"),
     ("ch_ckpt", scripts.camassa_holm.PI.PhysicsInformedNN, "pi"),
     ("gnss_w100_ckpt", scripts.gnss.sw.PhysicsInformedNN, "gnss_sw"),
+    ("gnss_bc_xavier", scripts.gnss.bc.bcPhysicsInformedNN, "gnss_bc"),
+    ("nls_w100_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_sw"),
 ])
 def test_class_backward_matches_reference(name, cls, kind):
     """The drop-in class on the GPU vs the reference's own backward() (fp64 golden)."""
@@ -355,6 +357,62 @@ def test_predict_known_answer_error_txt(golden_dir):
     err = np.linalg.norm(u_star - u, 2) / np.linalg.norm(u_star, 2)
     assert abs(err - 3.743270e-01) < 5e-7
     assert np.max(np.abs(u[g["sel"], 0] - g["u_pred_sel"])) < 2e-5 * np.max(np.abs(g["u_pred_sel"]))
+
+
+@pytest.mark.parametrize("eq", ["burgers", "kdv5", "kdv7_1sol", "kdv7_3sol", "gnss", "nls"])
+def test_residual_of_exact_solutions_vanishes_on_gpu(eq):
+    """pinn_residual_from_derivs (the Residual<EQ> device code the fused kernels inline) on exact solutions of
+    the PDEs as coded in the reference (oracle/gen_analytic.py): zero up to fp32 rounding, i.e. far below what
+    a 1 % error in the coefficients would leave behind, and equal to the fp64 oracle's polynomial on random
+    derivative vectors to 1e-6 of the largest term."""
+    from oracle.pyoracle import COEF
+    a = np.load(os.path.join(GOLDEN, "analytic_solutions.npz"))
+    der = a["derivs_" + eq]
+    layers = [2, 20, der.shape[1]]
+    lb, ub = np.array([-1.0, -1.0], dtype=np.float32), np.array([1.0, 1.0], dtype=np.float32)
+    eng = NativeEngine(equations.get(eq), layers, lb, ub, dev())
+    f = eng.residual_from_derivs(cu(der)).cpu().numpy()
+    wrong = Oracle(eq, layers, lb, ub, coef=[1.01 * c for c in COEF[eq][1]])
+    sens = np.abs(wrong.residual_from_derivs(der)).max()
+    assert np.abs(f).max() <= 2e-3 * sens
+    rng = np.random.default_rng(1)
+    rd = rng.standard_normal(der.shape)
+    o = Oracle(eq, layers, lb, ub)
+    fr = eng.residual_from_derivs(cu(rd)).cpu().numpy()
+    f64 = o.residual_from_derivs(rd.astype(np.float32).astype(np.float64))
+    assert np.abs(fr - f64).max() <= 1e-5 * np.abs(f64).max()
+
+
+def test_sliding_window_test_mode_error_txt_on_gpu(tmp_path):
+    """drivers.sliding_window(train=False) on the HIP path with the shipped sw73_{1,2,3}.pth:
+    error.txt:109-110, 'Overall Error u: 3.223475e-02' (7kdv/sw-73.py:343-376)."""
+    from test_drivers_cpu import run_sw73_test_mode
+    g, full, err = run_sw73_test_mode(scripts.for_script("7kdv/sw-73.py").PhysicsInformedNN, tmp_path)
+    assert abs(err - 3.223475e-02) < 5e-8 and abs(err - float(g["err_ref"])) < 1e-6 * err
+    assert np.max(np.abs(full[g["sel"], 0] - g["u_full_sel"])) < 2e-5 * np.max(np.abs(g["u_full_sel"]))
+
+
+def test_predict_known_answer_kdv5_on_gpu(golden_dir):
+    """error.txt:4 — 5kdv PINN1t-2.pth on the 201x512 grid -> 2.446954e-02, on the GPU."""
+    from pde_amd import drivers
+    g = np.load(os.path.join(golden_dir, "predict_kdv5.npz"))
+    m = scripts.for_script("5kdv/PI-51.py").PhysicsInformedNN(g["layers"].tolist(), g["lb"], g["ub"])
+    _load_theta(m, g["theta"])
+    err = drivers.relative_l2(m.predict(drivers.grid_points(g["x"], g["t"])), g["uu"].flatten()[:, None])
+    assert abs(err - 2.446954e-02) < 5e-8
+
+
+def test_load_model_reference_written_checkpoint_on_gpu(tmp_path, golden_dir):
+    """A .pth written by the reference's own save_model() loads through load_model() onto the GPU."""
+    import shutil
+    g = np.load(os.path.join(golden_dir, "ref_written_kdv7.npz"))
+    os.makedirs(os.path.join(str(tmp_path), "model"))
+    shutil.copy(os.path.join(golden_dir, "ref_written_kdv7.pth"), os.path.join(str(tmp_path), "model", "w.pth"))
+    cls = type("M", (scripts.for_script("7kdv/PI-7kdv3soliton.py").PhysicsInformedNN,), {"base_dir": str(tmp_path)})
+    m = cls(g["layers"].tolist(), g["lb"], g["ub"])
+    m.load_model("w.pth")
+    assert np.array_equal(m.dnn.flat_theta().cpu().numpy(), g["theta"])
+    assert np.max(np.abs(m.predict(g["X"]) - g["u"])) < 1e-5 * np.max(np.abs(g["u"]))
 
 
 def test_short_training_run_decreases_loss():

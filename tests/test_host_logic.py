@@ -50,6 +50,8 @@ CASES = [
     ("ch_bc_xavier", scripts.camassa_holm_bc.bc.PhysicsInformedNN, "pi"),
     ("gnss_w50_xavier", scripts.gnss.PI.PhysicsInformedNN, "gnss"),
     ("gnss_w100_ckpt", scripts.gnss.sw.PhysicsInformedNN, "gnss_sw"),
+    ("gnss_bc_xavier", scripts.gnss.bc.bcPhysicsInformedNN, "gnss_bc"),      # two-output bc class, NLS/bc-GNSS-torch.py:222-312
+    ("nls_w100_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_sw"),        # plain NLS (c = 0), NLS/sw-PINN-rogue.py
 ]
 
 
@@ -65,6 +67,9 @@ def feed(model, g, kind):
     elif kind == "bc":
         Xh = np.concatenate([d["x1"], d["t1"]], axis=1)
         model.set_training_data(d["x0"], d["u0"], float(d["t0"][0, 0]), d["u1"], d["tb"], Xf, Xh)
+    elif kind == "gnss_bc":
+        Xh = np.concatenate([d["x1"], d["t1"]], axis=1)
+        model.set_training_data(d["x0"], d["u0"], d["v0"], float(d["t0"][0, 0]), d["u1"], d["v1"], d["tb"], Xf, Xh)
     elif kind == "gnss":
         model.set_training_data(d["x0"], d["u0"], d["v0"], d["tb"], Xf)
     elif kind == "gnss_sw":

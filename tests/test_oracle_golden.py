@@ -116,3 +116,27 @@ def test_oracle_matches_reference_fp64_on_noise_batches(fn):
         e32[b] = np.linalg.norm(f32 - f64) / np.linalg.norm(f64)
     ref = np.sqrt(np.mean((g["ref_f_err"] / g["ref_f_norm"]) ** 2))
     assert np.sqrt(np.mean(e32 ** 2)) <= 4.0 * ref
+
+
+ANALYTIC = ["burgers", "kdv5", "kdv7_1sol", "kdv7_3sol", "gnss", "nls"]
+
+
+@pytest.mark.parametrize("eq", ANALYTIC)
+def test_residual_of_exact_solutions_vanishes(eq):
+    """Known answers that need no network: exact solutions of the PDEs as coded in the
+    reference — Burgers front, Sawada-Kotera / Lax-KdV7 two-solitons in the tau-function form of
+    soliton.py:8-25, Hirota and boosted NLS solitons — have zero residual (oracle/gen_analytic.py,
+    derivatives from sympy at 40 digits).  Scale: what a 1 % error in the coefficients would leave behind
+    on the same points; fp64 residual <= 1e-10 of it, fp32 <= 2e-3 of it."""
+    a = np.load(os.path.join(GOLDEN, "analytic_solutions.npz"))
+    der = a["derivs_" + eq]
+    layers = [2, 8, der.shape[1]]
+    o = Oracle(eq, layers, [-1.0, -1.0], [1.0, 1.0])
+    assert der.shape[2] == o.J
+    f64 = o.residual_from_derivs(der)
+    f32 = o.residual_from_derivs(der, dtype=np.float32)
+    wrong = Oracle(eq, layers, [-1.0, -1.0], [1.0, 1.0], coef=[1.01 * c for c in __import__("oracle.pyoracle", fromlist=["COEF"]).COEF[eq][1]])
+    sens = np.abs(wrong.residual_from_derivs(der)).max()          # what a 1 % coefficient error leaves behind
+    assert sens > 1e-4
+    assert np.abs(f64).max() <= 1e-10 * sens
+    assert np.abs(f32).max() <= 2e-3 * sens
