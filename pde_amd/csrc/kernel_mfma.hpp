@@ -344,7 +344,10 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     static_assert(!GROUPED || R * ZTL_J * 16 <= STAGE_TILE, "tail set does not fit the staging tile");
     float *const atl = GROUPED ? stage : lds + L.atl + wv * (R * ZTL_J * 16);
 
-    for (long long tile = wave_g; tile < ntiles; tile += nwaves) {
+    // Tiles are dealt to workgroups first and to the waves of a workgroup second (tile = block + grid * (wave +
+    // waves * k)): a launch with fewer tiles than wave slots (the scripts' N_f = 10 000 .. 16 000) then spreads
+    // over all CUs and over the four SIMDs of each CU before any SIMD has to interleave two tiles.
+    for (long long tile = blockIdx.x + (long long)gridDim.x * wv; tile < ntiles; tile += nwaves) {
         PINN_REFRESH();
         // (point index and validity are re-derived where they are needed again, not kept live)
         const long long pc = (tile * 16 + p < a.n) ? tile * 16 + p : a.n - 1;

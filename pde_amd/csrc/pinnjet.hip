@@ -203,8 +203,9 @@ int call_need(const pinn_handle *h, int eq, int mode, long long n, Need *nd)
     if (h->kernel == PINN_KERNEL_MFMA) {
         const long long ntiles = (n + 15) / 16;
         const int waves = mfma_waves(h->kd, J);
-        const long long need_blocks = (ntiles + waves - 1) / waves;
-        nd->grid = (int)(need_blocks < h->mfma_grid ? need_blocks : h->mfma_grid);
+        // one workgroup per CU at most; with fewer tiles than that, one tile per workgroup (the kernel deals
+        // tiles to workgroups first, to the waves of a workgroup second)
+        nd->grid = (int)(ntiles < h->mfma_grid ? ntiles : h->mfma_grid);
         nd->jets_per_wg = (mode != MODE_FWD) ? mfma_stash_floats(h->kd, J) * sizeof(float) * waves : 0;
         nd->zero_slab = (mode != MODE_FWD) && mfma_wglobal(h->kd);
         return PINN_OK;
