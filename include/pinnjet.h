@@ -175,6 +175,17 @@ int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const flo
 int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float *loss, float *out4,
                           void *stream);
 
+/* ---- Adam / AdamW on the device, one launch per step ------------------------------------
+ * Replaces torch.optim.Adam / AdamW(weight_decay=1e-2).step() of the reference's Adam phase
+ * (7kdv/PI-7kdv3soliton.py:138,154-157; 7kdv/sw73-adamW.py:170) for parameters held as ONE flat vector:
+ * the arithmetic of torch's default (non-amsgrad) Adam, decoupled != 0 selects AdamW's decay.  `state` is
+ * 32 bytes of device memory (zero it to start: step count and running beta powers in float64 + a ticket
+ * word); the step count advances on the device, so the call has no per-step host argument and replays from a
+ * captured graph.  exp_avg / exp_avg_sq: n floats each, zero-initialised by the caller. */
+int pinn_adam_step(float *theta, const float *grad, float *exp_avg, float *exp_avg_sq, double *state,
+                   int64_t n, float lr, double beta1, double beta2, float eps, float weight_decay,
+                   int32_t decoupled, void *stream);
+
 const char *pinn_error_string(int code);
 
 #define PINN_OK 0

@@ -37,7 +37,7 @@ _lib = None
 SYMBOLS = [
     "pinn_create", "pinn_destroy", "pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout",
     "pinn_kernel_kind", "pinn_forward", "pinn_forward_vjp", "pinn_residual_fwd", "pinn_residual_vjp",
-    "pinn_loss_grad", "pinn_error_string", "pinn_reserve", "pinn_forward_vjp_static", "pinn_residual_from_derivs",
+    "pinn_loss_grad", "pinn_error_string", "pinn_reserve", "pinn_forward_vjp_static", "pinn_residual_from_derivs", "pinn_adam_step",
     "pinn_lbfgs_workspace_floats", "pinn_lbfgs_direction", "pinn_lbfgs_eval_stats",
 ]
 
@@ -69,6 +69,7 @@ def load_library():
     lib.pinn_lbfgs_workspace_floats.restype = i64
     lib.pinn_lbfgs_direction.argtypes = [vp, i64, ctypes.c_int32, vp, vp, f32, ctypes.c_int32, vp, vp]
     lib.pinn_lbfgs_eval_stats.argtypes = [vp, vp, i64, vp, vp, vp]
+    lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, ctypes.c_double, ctypes.c_double, f32, f32, ctypes.c_int32, vp]
     lib.pinn_error_string.argtypes = [ctypes.c_int]
     lib.pinn_error_string.restype = ctypes.c_char_p
     _lib = lib

@@ -1,0 +1,93 @@
+"""Adam / AdamW for a net whose parameters are views of ONE flat buffer: one HIP launch per step.
+
+The reference's Adam phase is `torch.optim.Adam(self.dnn.parameters())` / `AdamW(..., weight_decay=1e-2)`
+(7kdv/PI-7kdv3soliton.py:138,154-157; 7kdv/sw73-adamW.py:170): ten parameter tensors, ~15 foreach launches per
+step.  `FusedAdam` has the same constructor arguments, the same update rule (torch's default, non-amsgrad
+Adam; `decoupled=True` is AdamW) and the usual `zero_grad()` / `step()` protocol; the step count lives on the
+device, so a captured HIP graph replays it as is.  There is no CPU fallback: it needs libpinnjet.so and a GPU.
+"""
+import ctypes
+
+import torch
+
+from ._native import NativeError, _check, load_library
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
+                 flat_params=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, decoupled=decoupled)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedAdam takes one parameter group")
+        self._params = self.param_groups[0]["params"]
+        if flat_params is None or not flat_params.is_cuda:
+            raise NativeError("FusedAdam needs the flat float32 CUDA buffer the parameters are views of; "
+                              "there is no CPU fallback (use torch.optim.Adam)")
+        off = 0
+        for p in self._params:
+            if p.data_ptr() != flat_params.data_ptr() + 4 * off or p.dtype != torch.float32:
+                raise ValueError("flat_params is not the buffer the parameters are views of")
+            off += p.numel()
+        if off != flat_params.numel():
+            raise ValueError("flat_params has %d elements, the parameters %d" % (flat_params.numel(), off))
+        self.lib = load_library()
+        self._x = flat_params
+        dev = flat_params.device
+        n = flat_params.numel()
+        self._g = torch.zeros(n, dtype=torch.float32, device=dev)
+        st = self.state[self._params[0]]
+        st["exp_avg"] = torch.zeros(n, dtype=torch.float32, device=dev)
+        st["exp_avg_sq"] = torch.zeros(n, dtype=torch.float32, device=dev)
+        st["device_state"] = torch.zeros(4, dtype=torch.float64, device=dev)   # step, beta1^t, beta2^t, ticket
+        self._attach_grads()
+
+    def _attach_grads(self):
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self._g.data_ptr() + 4 * off:
+                p.grad = self._g[off:off + n].view(p.shape)
+            off += n
+
+    def zero_grad(self, set_to_none=True):
+        """Zeroes the flat gradient; `.grad` stay views into it (one memset instead of ten)."""
+        self._g.zero_()
+        self._attach_grads()
+
+    def flat_grad(self):
+        return self._g
+
+    def _gather(self):
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            seg = self._g[off:off + n]
+            if p.grad is None:
+                seg.zero_()
+            elif p.grad.data_ptr() != seg.data_ptr():
+                seg.copy_(p.grad.reshape(-1))
+            off += n
+
+    @property
+    def step_count(self):
+        return int(self.state[self._params[0]]["device_state"][0].item())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._gather()
+        grp = self.param_groups[0]
+        st = self.state[self._params[0]]
+        dev = self._x.device
+        with torch.cuda.device(dev):
+            _check(self.lib.pinn_adam_step(self._x.data_ptr(), self._g.data_ptr(), st["exp_avg"].data_ptr(),
+                                           st["exp_avg_sq"].data_ptr(), st["device_state"].data_ptr(), self._x.numel(),
+                                           float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
+                                           float(grp["eps"]), float(grp["weight_decay"]), 1 if grp["decoupled"] else 0,
+                                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "pinn_adam_step")
+        return loss

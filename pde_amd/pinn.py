@@ -62,6 +62,7 @@ class PhysicsInformedNN:
     kernel = KERNEL_AUTO
     use_hip_graph = False            # train(): replay the Adam phase from a captured HIP graph (single process)
     hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
+    adam_impl = "fused"              # "fused": pde_amd.optim.FusedAdam (one launch per step); "torch": torch.optim.Adam/AdamW
     lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (one launch per direction); "torch": torch.optim.LBFGS
     lbfgs_kernels_factory = None     # test hook: callable(n, history) -> stand-in for the L-BFGS launches
     engine_factory = None            # test hook: callable(equation|None, layers, lb, ub, device) -> engine
@@ -422,7 +423,13 @@ class PhysicsInformedNN:
         self.dnn.train()
         self.iter = init_iter
         params = list(self.dnn.parameters())
-        if v.optimizer == "adamw":
+        self._fused_adam = self.adam_impl == "fused" and torch.device(self.device).type == "cuda"
+        if self._fused_adam:
+            # same update rule and defaults as torch.optim.Adam / AdamW(weight_decay=1e-2), one launch per step
+            from .optim import FusedAdam
+            self.optimizer_Adam = FusedAdam(params, flat_params=self.dnn.flat_theta(), decoupled=v.optimizer == "adamw",
+                                            weight_decay=v.weight_decay if v.optimizer == "adamw" else 0.0)
+        elif v.optimizer == "adamw":
             self.optimizer_Adam = torch.optim.AdamW(params, weight_decay=v.weight_decay)
         else:
             self.optimizer_Adam = torch.optim.Adam(params)
@@ -479,7 +486,9 @@ class PhysicsInformedNN:
         and step count of the warm-up iterations are kept."""
         v = self.variant
         kw = dict(capturable=True)
-        if v.optimizer == "adamw":
+        if self._fused_adam:
+            opt = self.optimizer_Adam            # its step count lives on the device: capturable as it is
+        elif v.optimizer == "adamw":
             opt = torch.optim.AdamW(params, weight_decay=v.weight_decay, **kw)
         else:
             opt = torch.optim.Adam(params, **kw)
@@ -501,6 +510,8 @@ class PhysicsInformedNN:
             graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
             with torch.cuda.graph(graph):
+                if self._fused_adam:
+                    opt.flat_grad().zero_()             # the flat gradient is a static buffer: cleared inside the graph
                 terms = self._loss_terms(overlap=True)
                 opt.step()
         except Exception as ex:                         # noqa: BLE001

@@ -191,3 +191,49 @@ def test_gnss_sliding_window_end_to_end(tmp_path):
     # the stitched field is what the reloaded window models predict
     _, (fu2, fv2, fh2), errs2 = drivers.sliding_window(cls, [2, 100, 100, 100, 100, 2], x, t, uu, train=False)
     assert np.allclose(fu2, fu, atol=1e-6) and np.allclose(fv2, fv, atol=1e-6) and np.allclose(errs2, errs, atol=1e-6)
+
+
+@pytest.mark.parametrize("adamw", [False, True])
+def test_fused_adam_follows_torch_adam(adamw):
+    """pde_amd.optim.FusedAdam (one launch per step, pinn_adam_step) against torch.optim.Adam / AdamW on the same
+    gradients: 60 steps on a flat 7 851-vector with a drifting synthetic gradient, parameters and both moments
+    agree to float32 rounding (1e-6 relative), the step count lives on the device."""
+    from pde_amd.optim import FusedAdam
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    n = 7851
+    flat = torch.randn(n, device=dev) * 0.3
+    shapes = [(50, 2), (50,), (50, 50), (50,), (50, 50), (50,), (50, 50), (50,), (1, 50), (1,)]
+    def views(buf):
+        out, off = [], 0
+        for sh in shapes:
+            k = int(np.prod(sh))
+            out.append(torch.nn.Parameter(buf[off:off + k].view(sh)))
+            off += k
+        return out
+    fa_buf, ta_buf = flat.clone(), flat.clone()
+    pf, pt = views(fa_buf), views(ta_buf)
+    kw = dict(weight_decay=1e-2) if adamw else {}
+    fa = FusedAdam(pf, flat_params=fa_buf, decoupled=adamw, **kw)
+    ta = (torch.optim.AdamW if adamw else torch.optim.Adam)(pt, **kw)
+    for it in range(60):
+        g = torch.sin(torch.arange(n, device=dev) * 0.01 + it) * (1.0 + 0.1 * it) + 0.05 * fa_buf.detach()
+        fa.zero_grad()
+        fa.flat_grad().add_(g)
+        ta.zero_grad()
+        off = 0
+        for p in pt:
+            k = p.numel()
+            p.grad = g[off:off + k].view(p.shape).clone()
+            off += k
+        fa.step()
+        ta.step()
+    torch.cuda.synchronize()
+    assert fa.step_count == 60
+    ref = ta_buf.detach().double()
+    assert float((fa_buf.detach().double() - ref).norm() / ref.norm()) < 1e-6
+    m_ref = torch.cat([ta.state[p]["exp_avg"].reshape(-1) for p in pt]).double()
+    v_ref = torch.cat([ta.state[p]["exp_avg_sq"].reshape(-1) for p in pt]).double()
+    st = fa.state[pf[0]]
+    assert float((st["exp_avg"].double() - m_ref).norm() / m_ref.norm()) < 1e-6
+    assert float((st["exp_avg_sq"].double() - v_ref).norm() / v_ref.norm()) < 1e-6
