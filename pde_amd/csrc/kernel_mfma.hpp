@@ -112,6 +112,7 @@ struct MfmaLayout {   // offsets in floats into dynamic LDS
     int ztl;          // per wave [R][J][16]: tail rows of Zb, [component][point], for the weight-gradient phase
     int atl;          // per wave [R][J][16]: the tail registers, parked while the tiled neurons are processed
     int total;
+    bool wglobal;     // main blocks of the weight gradients go to the workgroup's global slab by float atomics (no `wimg`)
 };
 
 template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &d, int J)
@@ -129,7 +130,14 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     L.gs_loss = L.gs_out + d.nout * W + d.nout;
     L.gs_size = ((L.gs_loss + 2 + 3) / 4) * 4;
     off += L.gs_size;
-    L.wimg = off; off += C::WGLOBAL ? 0 : (d.n_lin - 2) * C::NT * C::NT * 256;
+    // The accumulator images are the one big LDS consumer that can move: wide layers never have them, and a
+    // deep net whose weights + images + staging would not fit (64 x 5 / 64 x 6, 7kdv/bc-7kdv3soliton.py:366)
+    // accumulates in its global slab like the wide shapes do, instead of falling back to the VALU kernels.
+    const int images = (d.n_lin - 2) * C::NT * C::NT * 256;
+    const int rest = ((d.n_lin - 2 + 3) / 4) * 4 + 4 + C::waves(J) * C::stg(J) * STAGE_TILE + (C::PARK ? C::waves(J) * 128 : 0)
+                     + C::waves(J) * C::R * J * 16 * (C::PARK ? 2 : 1);
+    L.wglobal = C::WGLOBAL || (off + images + rest) * 4 > MFMA_LDS_LIMIT;
+    L.wimg = off; off += L.wglobal ? 0 : images;
     L.locks = off; off += ((d.n_lin - 2 + 3) / 4) * 4 + 4;
     L.stage = off; off += C::waves(J) * C::stg(J) * STAGE_TILE;
     L.xt = off; off += C::PARK ? C::waves(J) * 128 : 0;
@@ -898,7 +906,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                     PINN_JB();
                 }
                 // accumulator (To,Ti): lane (i = p, q) register r holds Wb[16To + 4q + r][16Ti + p]
-                if (WGLOBAL) {
+                if (WGLOBAL || L.wglobal) {
                     {
                         // buffer atomics: one per-lane offset VGPR, everything else scalar
                         const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + 2) * 4, 0x00020000);
@@ -1199,7 +1207,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                         else if (l == n_lin - 1) v = gs[L.gs_out + rel];
                         else if (o >= NM) v = gblock(l)[W + (o - NM) * W + c];
                         else if (c >= NM) v = gblock(l)[W + R * W + o * R + (c - NM)];
-                        else if (WGLOBAL) continue;      // went to the (pre-zeroed) slab directly, by hardware atomics
+                        else if (WGLOBAL || L.wglobal) continue;   // went to the (pre-zeroed) slab directly, by hardware atomics
                         else {
                             // accumulator (To,Ti): lane (p, q) register r holds Wb[16To + 4q + r][16Ti + p]
                             const int To = o >> 4, q4 = (o & 15) >> 2, r = o & 3, Ti = c >> 4, pp = c & 15;
@@ -1235,10 +1243,10 @@ inline int mfma_waves(const KDesc &kd, int J)
     default: return MFMA_MAX_WAVES;
     }
 }
-inline bool mfma_wglobal(const KDesc &kd)
+inline bool mfma_wglobal(const KDesc &kd, int J)
 {
     switch (kd.widths[1]) {
-#define X(w) case w: return WidthCfg<w>::WGLOBAL;
+#define X(w) case w: return mfma_layout<w>(kd, J).wglobal;
         PINN_MFMA_WIDTHS(X)
 #undef X
     default: return false;

@@ -207,7 +207,7 @@ int call_need(const pinn_handle *h, int eq, int mode, long long n, Need *nd)
         // tiles to workgroups first, to the waves of a workgroup second)
         nd->grid = (int)(ntiles < h->mfma_grid ? ntiles : h->mfma_grid);
         nd->jets_per_wg = (mode != MODE_FWD) ? mfma_stash_floats(h->kd, J) * sizeof(float) * waves : 0;
-        nd->zero_slab = (mode != MODE_FWD) && mfma_wglobal(h->kd);
+        nd->zero_slab = (mode != MODE_FWD) && mfma_wglobal(h->kd, J);
         return PINN_OK;
     }
 #endif

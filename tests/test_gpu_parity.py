@@ -181,6 +181,7 @@ def test_ragged_sizes_against_oracle(name, kname, kernel):
 @pytest.mark.parametrize("eq,width,depth", [
     ("kdv7_3sol", 50, 1), ("kdv7_3sol", 50, 2), ("kdv7_3sol", 50, 6),     # 1 / 2 / 6 tanh layers (bc nets use 5-6)
     ("ch", 64, 1), ("ch", 64, 2), ("ch", 64, 6),
+    ("kdv7_3sol", 64, 5), ("kdv7_3sol", 64, 6),                               # the 6 x 64 net of 7kdv/bc-7kdv3soliton.py:366 (global-slab accumulation)
     ("gnss", 100, 1), ("gnss", 100, 2), ("gnss", 100, 4), ("gnss", 50, 5), ("burgers", 100, 3),
     ("burgers", 20, 1), ("burgers", 20, 8), ("kdv5", 20, 3),                 # width 20 = one MFMA tile + 4 tail neurons
 ])
@@ -221,35 +222,40 @@ def test_mfma_depths_against_oracle(eq, width, depth):
         assert rel(grad.cpu().numpy(), gref) < tol, (n, "grad")
 
 
-@pytest.mark.parametrize("kname,kernel", KINDS)
-def test_full_size_properties(kname, kernel):
-    """BASELINE config sizes are too big for the oracle; use size-independent
-    properties: (a) additivity over shards: loss_grad(N) == loss_grad(first half) +
-    loss_grad(second half); (b) a 4096-point random subsample of f against the
-    oracle; (c) linearity of the vjp in the cotangent."""
-    g = np.load(os.path.join(GOLDEN, "kdv7_3sol_ckpt.npz"))
+FULL_SIZE = [("kdv7_3sol_ckpt", "valu", KERNEL_VALU, 200_000), ("kdv7_3sol_ckpt", "mfma", KERNEL_MFMA, 1_000_000),
+             ("gnss_w100_ckpt", "mfma", KERNEL_MFMA, 2_000_000), ("ch_w64_xavier", "mfma", KERNEL_MFMA, 1_250_000),
+             ("kdv5_ckpt", "mfma", KERNEL_MFMA, 100_000), ("burgers_9x20_xavier", "mfma", KERNEL_MFMA, 10_000)]
+
+
+@pytest.mark.parametrize("name,kname,kernel,N", FULL_SIZE)
+def test_full_size_properties(name, kname, kernel, N):
+    """BASELINE config sizes (7kdv 1M, GNSS 2M, CH 1.25M per GPU, 5kdv 100k, Burgers 10k) are too big for the
+    oracle; use size-independent properties: (a) additivity over shards: loss_grad(N) == loss_grad(first part)
+    + loss_grad(second part); (b) a 4096-point random subsample of f against the fp64 oracle; (c) linearity
+    of the vjp in the cotangent."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
     eng = engine_for(g, kernel)
-    N = 1_000_000 if kernel == KERNEL_MFMA else 200_000
+    eq = str(g["eq"])
     rng = np.random.default_rng(1234)
     X = (g["lb"] + (g["ub"] - g["lb"]) * rng.random((N, 2))).astype(np.float32)
     x, t, theta = cu(X[:, 0]), cu(X[:, 1]), cu(g["theta"])
-    full = torch.zeros(eng.P + 1, device=dev())
+    full = torch.zeros(eng.P + eng.nf, device=dev())
     eng.loss_grad(theta, x, t, 1.0 / N, full[eng.P:], full[:eng.P])
-    halves = torch.zeros(eng.P + 1, device=dev())
+    halves = torch.zeros(eng.P + eng.nf, device=dev())
     h = N // 2 + 13
     eng.loss_grad(theta, x[:h], t[:h], 1.0 / N, halves[eng.P:], halves[:eng.P])
     eng.loss_grad(theta, x[h:], t[h:], 1.0 / N, halves[eng.P:], halves[:eng.P])
     torch.cuda.synchronize()
     assert rel(halves.cpu().numpy(), full.cpu().numpy().astype(np.float64)) < 2e-5
-    sel = rng.choice(N, 4096, replace=False)
+    sel = rng.choice(N, min(4096, N), replace=False)
     f = eng.residual_fwd(theta, x, t).cpu().numpy()[sel]
-    o = Oracle("kdv7_3sol", g["layers"].tolist(), g["lb"], g["ub"])
+    o = Oracle(eq, g["layers"].tolist(), g["lb"], g["ub"])
     der64, f64 = o.forward(g["theta"].astype(np.float64), X[sel, 0], X[sel, 1])
     scale = max(np.linalg.norm(der64[:, :, j]) for j in range(der64.shape[2]))
     assert np.linalg.norm(f - f64) <= 1e-5 * scale
-    n2 = 50_000
-    g1 = cu(rng.standard_normal((n2, 1)))
-    g2 = cu(rng.standard_normal((n2, 1)))
+    n2 = min(50_000, N)
+    g1 = cu(rng.standard_normal((n2, eng.nf)))
+    g2 = cu(rng.standard_normal((n2, eng.nf)))
     o1 = torch.zeros(eng.P, device=dev()); o2 = torch.zeros(eng.P, device=dev()); o3 = torch.zeros(eng.P, device=dev())
     eng.residual_vjp(theta, x[:n2], t[:n2], g1, o1)
     eng.residual_vjp(theta, x[:n2], t[:n2], g2, o2)
