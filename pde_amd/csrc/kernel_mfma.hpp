@@ -450,14 +450,11 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                     tanh_jet_fwd<K, KT, ZN0, ZTN0>(z, y, w);
 #pragma unroll
                     for (int j = 0; j < J; ++j) pin(y[j]);
-                    if (topl) {
-                        out_acc_main(16 * T + 4 * q + r, y);
+                    // (a select, not two branches writing A: merging the branches made the compiler copy the whole
+                    // tile's registers back and forth once per neuron)
+                    if (topl) out_acc_main(16 * T + 4 * q + r, y);
 #pragma unroll
-                        for (int j = 0; j < J; ++j) A[T][j][r] = z[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < J; ++j) A[T][j][r] = y[j];
-                    }
+                    for (int j = 0; j < J; ++j) A[T][j][r] = topl ? z[j] : y[j];
                     PINN_SB();
                 }
                 if (keep_y) {
@@ -577,12 +574,9 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                     tanh_jet_fwd<K, KT>(z, y, w);
 #pragma unroll
                     for (int j = 0; j < J; ++j) pin(y[j]);
-                    if (topl) {
-                        out_acc_main(16 * To + 4 * q + r, y);
-                    } else {
+                    if (topl) out_acc_main(16 * To + 4 * q + r, y);
 #pragma unroll
-                        for (int j = 0; j < J; ++j) A[To][j][r] = y[j];
-                    }
+                    for (int j = 0; j < J; ++j) A[To][j][r] = topl ? z[j] : y[j];
                     PINN_SB();
                     if (r == 3 && keep_y) {
 #pragma unroll
