@@ -62,14 +62,14 @@ def cpu_baseline(w, budget_s=25.0):
     torch_ref.loss_f_and_grad(w["eq"], net, x[:2000], t[:2000])  # warm-up
     times = []
     t_start = time.time()
-    while len(times) < 3 and (time.time() - t_start) < budget_s:
+    while len(times) < 8 and (time.time() - t_start) < budget_s:
         t0 = time.time()
         torch_ref.loss_f_and_grad(w["eq"], net, x, t)
         times.append(time.time() - t0)
     per = float(np.median(times))
     out = {"value": n / per, "unit": "collocation evals/s", "cores": cores, "kind": "port",
-           "sample": "%d closures of nested-autograd net_f+backward at N=%d (oracle/torch_ref.py, fp32, torch CPU)"
-                     % (len(times), n)}
+           "sample": "median of %d closures of nested-autograd net_f+backward at N=%d (oracle/torch_ref.py, fp32, torch CPU; "
+                     "fastest %.3e, slowest %.3e evals/s)" % (len(times), n, n / min(times), n / max(times))}
     # the C Taylor-jet oracle (same algorithm as the kernels) on the same cores, for context
     try:
         from oracle.pyoracle import Oracle
@@ -143,7 +143,8 @@ def main():
         n_global = args.points or {"ch": 10_000_000}.get(args.workload, w["n"])
         q, rem = divmod(n_global, world)
         n_local = q + (1 if rank < rem else 0)
-        w["name"] += " [strong scaling: %d points in total over %d GPU(s)]" % (n_global, world)
+        w["name"] = w["name"].replace(" per GPU", "").replace("N_f=1.25M (10M over 8)", "N_f=10M") \
+            + " [strong scaling: %d points in total over %d GPU(s)]" % (n_global, world)
     else:
         if args.points:
             w["n"] = args.points
