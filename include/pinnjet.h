@@ -49,7 +49,8 @@ enum {
     PINN_EQ_KDV5 = 2,    /* 5kdv/PI-51.py:132-140                       coef[0..3]=180,30,30,1   */
     PINN_EQ_KDV7 = 3,    /* 7kdv/PI-7kdv3soliton.py:122-132 / PI-7kdv1soliton.py:132  coef[0..7] */
     PINN_EQ_CH = 4,      /* CH/PI-CH-1soliton.py:131-138 (coef[0]=0), CH/bc-CH-1soliton.py:270-278 (coef[0]=2) */
-    PINN_EQ_GNSS = 5     /* NLS/sw-GNSS-adamW.py:159-180   coef[0..2]=a,b,c (c=0: plain NLS)     */
+    PINN_EQ_GNSS = 5,    /* NLS/sw-GNSS-adamW.py:159-180   coef[0..2]=a,b,c (c=0: plain NLS)     */
+    PINN_EQ_LPD = 6      /* NLS/Ibc-test.py:163-164, NLS/testGNSS.py:139-140 (4th order)  coef[0..5]=0.5,1,0.125,0.0625,6,10 */
 };
 
 /* kernel selection.  The FP32-MFMA kernels are instantiated for nets whose hidden layers all have

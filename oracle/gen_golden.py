@@ -110,6 +110,9 @@ def eval_case(mod, cls_name, layers, lb, ub, ckpt, seed, eq, K, KT, pts, extra, 
             for k, v in extra.items():
                 if v is None:
                     setattr(model, k, None)
+                elif k == "earliest_solutions":       # NLS/IBCtest.py:225: a list of (X_ref, h_ref) tensor pairs
+                    setattr(model, k, [tuple(torch.tensor(np.asarray(a, dtype=np.float32).astype(np.float64)).to(dtype)
+                                             for a in pair) for pair in v])
                 else:
                     setattr(model, k, torch.tensor(np.asarray(v, dtype=np.float32).astype(np.float64)).to(dtype))
             model.xf, model.tf = x, t
@@ -120,7 +123,11 @@ def eval_case(mod, cls_name, layers, lb, ub, ckpt, seed, eq, K, KT, pts, extra, 
             out["grad_full" + tag] = flat_grad(model)
     if extra is not None:
         for k, v in extra.items():
-            if v is not None:
+            if k == "earliest_solutions":
+                for i, (X, h) in enumerate(v):
+                    out["data_es_X%d" % i] = np.asarray(X, dtype=np.float32)
+                    out["data_es_h%d" % i] = np.asarray(h, dtype=np.float32)
+            elif v is not None:
                 out["data_" + k] = np.asarray(v, dtype=np.float32)
     return out
 
@@ -296,6 +303,33 @@ def main():
     cases.append(("nls_w100_xavier", "nls", L100, lb, ub,
                   eval_case(mnls, "PhysicsInformedNN", L100, lb, ub, None, 1357, "gnss", 3, 1, pts, ex),
                   "NLS/sw-PINN-rogue.py + xavier(manual_seed 1357)"))
+
+    # ---- 4th-order NLS of the scratch scripts (optional id), NLS/Ibc-test.py:222-313 (bc class) ----------
+    mlpd = load_script("NLS/Ibc-test.py")
+    lb, ub = np.array([-5.0, -5.0]), np.array([5.0, 5.0])
+    pts = sample_points(lb, ub, N_PTS, rng)
+    ex = data_terms(rng, lb, ub, -5.0, 2)
+    Xh = sample_points(lb, ub, 40, rng)
+    ex["x1"], ex["t1"] = Xh[:, 0:1], Xh[:, 1:2]
+    ex["u1"] = (0.5 * np.cos(Xh[:, 0:1]) / np.cosh(0.3 * Xh[:, 1:2])).astype(np.float32)
+    ex["v1"] = (0.3 * np.sin(Xh[:, 0:1] + 0.2 * Xh[:, 1:2])).astype(np.float32)
+    cases.append(("lpd_w50_xavier", "lpd", L502, lb, ub,
+                  eval_case(mlpd, "bcPhysicsInformedNN", L502, lb, ub, None, 8642, "lpd", 4, 1, pts, ex),
+                  "NLS/Ibc-test.py bcPhysicsInformedNN (4th-order residual :311-312, loss1) + xavier(manual_seed 8642)"))
+
+    # ---- list-of-reference-terms loss_s, NLS/IBCtest.py:203-291 (IbcPhysicsInformedNN, plain NLS residual) ------
+    mibc = load_script("NLS/IBCtest.py")
+    lb, ub = np.array([-5.0, -1.0]), np.array([5.0, 1.0])
+    mibc.t0_val = -1.0
+    pts = sample_points(lb, ub, N_PTS, rng)
+    ex = data_terms(rng, lb, ub, -1.0, 2)
+    Xa, Xb = sample_points(lb, ub, 30, rng), sample_points(lb, ub, 17, rng)
+    ex["earliest_solutions"] = [     # h_ref = |psi| has ONE column (:444-449): torch broadcasts it against (N, 2)
+        (Xa, (0.9 / np.cosh(Xa[:, 0:1])).astype(np.float32)),
+        (Xb, (0.4 + 0.1 * np.cos(Xb[:, 0:1] * Xb[:, 1:2])).astype(np.float32))]
+    cases.append(("nls_ibc_xavier", "nls", L502, lb, ub,
+                  eval_case(mibc, "IbcPhysicsInformedNN", L502, lb, ub, None, 9753, "gnss", 3, 1, pts, ex),
+                  "NLS/IBCtest.py IbcPhysicsInformedNN (loss_s over a list of (X_ref, h_ref)) + xavier(manual_seed 9753)"))
 
     only = os.environ.get("GEN_GOLDEN_ONLY")          # e.g. "gnss_bc_xavier,nls_w100_xavier": write just these
     for name, eq, layers, lb, ub, arrs, src in cases:

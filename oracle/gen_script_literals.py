@@ -18,7 +18,8 @@ SCRIPTS = sorted(
     glob.glob(os.path.join(REF, "7kdv", "*.py")) + glob.glob(os.path.join(REF, "5kdv", "*.py"))
     + glob.glob(os.path.join(REF, "CH", "*.py"))
     + [os.path.join(REF, "NLS", f) for f in ("PI-GNSS-torch.py", "bc-GNSS-torch.py", "sw-GNSS.py", "sw-GNSS-adamW.py",
-                                              "sw-PINN-rogue.py")]
+                                              "sw-PINN-rogue.py",
+                                              "Ibc-test.py")]       # scratch copy kept for its 4th-order residual id
     + [os.path.join(REF, "Burgers", "Burgers_equation(PINN).py")])
 
 
@@ -75,6 +76,8 @@ def parse_class(name, start, body):
                 eq = "ch_bc" if "+2*u_x" in sq else "ch"
             elif "self.nu*u_xx" in sq:
                 eq = "burgers"
+            elif sq.startswith("fu=u_t+0.5*v_xx+(u**2+v**2)*v+0.0625*(v_xxxx"):
+                eq = "lpd"
             elif sq.startswith("fu=u_t+0.5*v_xx+(u**2+v**2)*v"):
                 eq = "gnss" if "-0.1*(u_xxx+6*(u**2+v**2)*u_x)" in sq else "nls"
             else:

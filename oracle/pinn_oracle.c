@@ -30,6 +30,7 @@ int orc_orders(const orc_desc *d, int *K, int *KT, int *nf)
     case ORC_EQ_KDV7:    *K = 7; *KT = 1; *nf = 1; break;
     case ORC_EQ_CH:      *K = 3; *KT = 3; *nf = 1; break;
     case ORC_EQ_GNSS:    *K = 3; *KT = 1; *nf = 2; if (nout != 2) return -1; break;
+    case ORC_EQ_LPD:     *K = 4; *KT = 1; *nf = 2; if (nout != 2) return -1; break;
     default: return -1;
     }
     return 0;

@@ -13,7 +13,8 @@ enum {
     ORC_EQ_KDV7 = 3,    /* coef[0..7]: 3-soliton 5/98,5/14,10/7,5/14,5,3,1,1;
                                        1-soliton 140,70,280,70,70,42,14,1                */
     ORC_EQ_CH = 4,      /* coef[0] = kappa (0 for PI script, 2 for the bc script)        */
-    ORC_EQ_GNSS = 5     /* coef[0..2] = a(0.5), b(1), c(0.1; 0 gives plain NLS)          */
+    ORC_EQ_GNSS = 5,    /* coef[0..2] = a(0.5), b(1), c(0.1; 0 gives plain NLS)          */
+    ORC_EQ_LPD = 6      /* coef[0..5] = a, b, c3, c4, p, q = 0.5, 1, 0.125, 0.0625, 6, 10 */
 };
 
 typedef struct {

@@ -169,6 +169,47 @@ static void SFX(residual)(const orc_desc *d, int K, int KT,
             Db[1][3] += g1 * (-cc);
         }
     } break;
+    case ORC_EQ_LPD: { /* NLS/Ibc-test.py:163-164, NLS/testGNSS.py:139-140 (as coded: 6 rho v_xx but 10 rho u_xx):
+                          fu = u_t + a v_xx + b rho v + c4 Gv - c3 (u_xxx + 6 rho u_x)
+                          fv = v_t - a u_xx - b rho u - c4 Gu - c3 (v_xxx + 6 rho v_x)
+                          Gv = v_4 + 6v(v_x^2-u_x^2) + 12 u u_x v_x + 4v(u_x^2+v_x^2) + p rho v_xx + 6 rho^2 v, Gu likewise */
+        const REAL *v = D[1];
+        REAL a = c[0], b = c[1], c3 = c[2], c4 = c[3], pp = c[4], qq = c[5];
+        REAL rho = u[0] * u[0] + v[0] * v[0];
+        REAL Gv = v[4] + (REAL)6 * v[0] * (v[1] * v[1] - u[1] * u[1]) + (REAL)12 * u[0] * u[1] * v[1]
+                + (REAL)4 * v[0] * (u[1] * u[1] + v[1] * v[1]) + pp * rho * v[2] + (REAL)6 * rho * rho * v[0];
+        REAL Gu = u[4] + (REAL)6 * u[0] * (u[1] * u[1] - v[1] * v[1]) + (REAL)12 * v[0] * u[1] * v[1]
+                + (REAL)4 * u[0] * (u[1] * u[1] + v[1] * v[1]) + qq * rho * u[2] + (REAL)6 * rho * rho * u[0];
+        f[0] = T[0][0] + a * v[2] + b * rho * v[0] + c4 * Gv - c3 * (u[3] + (REAL)6 * rho * u[1]);
+        f[1] = T[1][0] - a * u[2] - b * rho * u[0] - c4 * Gu - c3 * (v[3] + (REAL)6 * rho * v[1]);
+        if (fb) {
+            REAL g0 = fb[0], g1 = fb[1];
+            REAL Gv_u0 = (REAL)12 * u[1] * v[1] + (REAL)2 * pp * u[0] * v[2] + (REAL)24 * rho * u[0] * v[0];
+            REAL Gv_v0 = (REAL)10 * v[1] * v[1] - (REAL)2 * u[1] * u[1] + (REAL)2 * pp * v[0] * v[2]
+                       + (REAL)24 * rho * v[0] * v[0] + (REAL)6 * rho * rho;
+            REAL Gv_u1 = (REAL)(-4) * v[0] * u[1] + (REAL)12 * u[0] * v[1];
+            REAL Gv_v1 = (REAL)20 * v[0] * v[1] + (REAL)12 * u[0] * u[1];
+            REAL Gu_u0 = (REAL)10 * u[1] * u[1] - (REAL)2 * v[1] * v[1] + (REAL)2 * qq * u[0] * u[2]
+                       + (REAL)24 * rho * u[0] * u[0] + (REAL)6 * rho * rho;
+            REAL Gu_v0 = (REAL)12 * u[1] * v[1] + (REAL)2 * qq * v[0] * u[2] + (REAL)24 * rho * u[0] * v[0];
+            REAL Gu_u1 = (REAL)20 * u[0] * u[1] + (REAL)12 * v[0] * v[1];
+            REAL Gu_v1 = (REAL)(-4) * u[0] * v[1] + (REAL)12 * v[0] * u[1];
+            Tb[0][0] += g0;
+            Tb[1][0] += g1;
+            Db[0][0] += g0 * ((REAL)2 * b * u[0] * v[0] + c4 * Gv_u0 - (REAL)12 * c3 * u[0] * u[1])
+                      + g1 * (-b * (rho + (REAL)2 * u[0] * u[0]) - c4 * Gu_u0 - (REAL)12 * c3 * u[0] * v[1]);
+            Db[1][0] += g0 * (b * (rho + (REAL)2 * v[0] * v[0]) + c4 * Gv_v0 - (REAL)12 * c3 * v[0] * u[1])
+                      + g1 * ((REAL)(-2) * b * v[0] * u[0] - c4 * Gu_v0 - (REAL)12 * c3 * v[0] * v[1]);
+            Db[0][1] += g0 * (c4 * Gv_u1 - (REAL)6 * c3 * rho) + g1 * (-c4 * Gu_u1);
+            Db[1][1] += g0 * (c4 * Gv_v1) + g1 * (-c4 * Gu_v1 - (REAL)6 * c3 * rho);
+            Db[1][2] += g0 * (a + c4 * pp * rho);
+            Db[0][2] += g1 * (-a - c4 * qq * rho);
+            Db[0][3] += g0 * (-c3);
+            Db[1][3] += g1 * (-c3);
+            Db[1][4] += g0 * c4;
+            Db[0][4] += g1 * (-c4);
+        }
+    } break;
     default: break;
     }
 }

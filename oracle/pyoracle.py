@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpinn_oracle.so")
 
-EQ_NONE, EQ_BURGERS, EQ_KDV5, EQ_KDV7, EQ_CH, EQ_GNSS = range(6)
+EQ_NONE, EQ_BURGERS, EQ_KDV5, EQ_KDV7, EQ_CH, EQ_GNSS, EQ_LPD = range(7)
 
 # residual coefficient sets, cited from the reference
 COEF = {
@@ -26,9 +26,10 @@ COEF = {
     "ch_bc": (EQ_CH, [2.0]),                                 # CH/bc-CH-1soliton.py:278
     "gnss": (EQ_GNSS, [0.5, 1.0, 0.1]),                      # NLS/sw-GNSS-adamW.py:178-179
     "nls": (EQ_GNSS, [0.5, 1.0, 0.0]),                       # NLS/sw-PINN-rogue.py:179-180
+    "lpd": (EQ_LPD, [0.5, 1.0, 0.125, 0.0625, 6.0, 10.0]),   # NLS/Ibc-test.py:163-164, NLS/testGNSS.py:139-140
     "none": (EQ_NONE, []),
 }
-ORDERS = {EQ_NONE: (0, 0), EQ_BURGERS: (2, 1), EQ_KDV5: (5, 1), EQ_KDV7: (7, 1), EQ_CH: (3, 3), EQ_GNSS: (3, 1)}
+ORDERS = {EQ_NONE: (0, 0), EQ_BURGERS: (2, 1), EQ_KDV5: (5, 1), EQ_KDV7: (7, 1), EQ_CH: (3, 3), EQ_GNSS: (3, 1), EQ_LPD: (4, 1)}
 
 
 class _Desc(ctypes.Structure):
@@ -76,7 +77,7 @@ class Oracle:
         self.K, self.KT = ORDERS[eq_id]
         self.J = self.K + 1 + self.KT
         self.nout = self.layers[-1]
-        self.nf = {EQ_NONE: self.nout, EQ_GNSS: 2}.get(eq_id, 1)
+        self.nf = {EQ_NONE: self.nout, EQ_GNSS: 2, EQ_LPD: 2}.get(eq_id, 1)
         d = _Desc()
         d.eq = eq_id
         d.n_lin = len(layers) - 1

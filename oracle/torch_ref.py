@@ -103,9 +103,10 @@ COEF = {
     "ch_bc": [2.0],
     "gnss": [0.5, 1.0, 0.1],
     "nls": [0.5, 1.0, 0.0],
+    "lpd": [0.5, 1.0, 0.125, 0.0625, 6.0, 10.0],
 }
 ORDERS = {"burgers": (2, 1), "kdv5": (5, 1), "kdv7_3sol": (7, 1), "kdv7_1sol": (7, 1),
-          "ch": (3, 3), "ch_bc": (3, 3), "gnss": (3, 1), "nls": (3, 1)}
+          "ch": (3, 3), "ch_bc": (3, 3), "gnss": (3, 1), "nls": (3, 1), "lpd": (4, 1)}
 
 
 def net_f(eq, net, x, t, coef=None):
@@ -129,6 +130,17 @@ def net_f(eq, net, x, t, coef=None):
         rho = u[0] ** 2 + v[0] ** 2
         fu = ut[0] + c[0] * v[2] + c[1] * rho * v[0] - c[2] * (u[3] + 6 * rho * u[1])
         fv = vt[0] - c[0] * u[2] - c[1] * rho * u[0] - c[2] * (v[3] + 6 * rho * v[1])
+        return [fu, fv]
+    if eq == "lpd":   # NLS/Ibc-test.py:163-164 as coded
+        v, vt = d[1]
+        rho = u[0] ** 2 + v[0] ** 2
+        a, b, c3, c4, pp, qq = c
+        Gv = v[4] + 6 * v[0] * (v[1] ** 2 - u[1] ** 2) + 12 * u[0] * u[1] * v[1] + 4 * v[0] * (u[1] ** 2 + v[1] ** 2) \
+            + pp * rho * v[2] + 6 * rho ** 2 * v[0]
+        Gu = u[4] + 6 * u[0] * (u[1] ** 2 - v[1] ** 2) + 12 * v[0] * u[1] * v[1] + 4 * u[0] * (u[1] ** 2 + v[1] ** 2) \
+            + qq * rho * u[2] + 6 * rho ** 2 * u[0]
+        fu = ut[0] + a * v[2] + b * rho * v[0] + c4 * Gv - c3 * (u[3] + 6 * rho * u[1])
+        fv = vt[0] - a * u[2] - b * rho * u[0] - c4 * Gu - c3 * (v[3] + 6 * rho * v[1])
         return [fu, fv]
     raise ValueError(eq)
 

@@ -12,7 +12,7 @@
 
 namespace pinn {
 
-enum { EQ_NONE = 0, EQ_BURGERS = 1, EQ_KDV5 = 2, EQ_KDV7 = 3, EQ_CH = 4, EQ_GNSS = 5 };
+enum { EQ_NONE = 0, EQ_BURGERS = 1, EQ_KDV5 = 2, EQ_KDV7 = 3, EQ_CH = 4, EQ_GNSS = 5, EQ_LPD = 6 };
 
 template <int EQ> struct EqTraits;
 template <> struct EqTraits<EQ_NONE>    { static constexpr int K = 0, KT = 0; };
@@ -21,6 +21,7 @@ template <> struct EqTraits<EQ_KDV5>    { static constexpr int K = 5, KT = 1; };
 template <> struct EqTraits<EQ_KDV7>    { static constexpr int K = 7, KT = 1; };
 template <> struct EqTraits<EQ_CH>      { static constexpr int K = 3, KT = 3; };
 template <> struct EqTraits<EQ_GNSS>    { static constexpr int K = 3, KT = 1; };
+template <> struct EqTraits<EQ_LPD>     { static constexpr int K = 4, KT = 1; };
 
 constexpr int MAXOUT = 2;
 
@@ -303,6 +304,60 @@ template <> struct Residual<EQ_GNSS> {  // NLS/sw-GNSS-adamW.py:159-180 (c[2]=0:
         Db[0][2] -= g1 * a;
         Db[0][3] -= g0 * cc;
         Db[1][3] -= g1 * cc;
+    }
+};
+
+// Fourth-order (Lakshmanan-Porsezian-Daniel type) NLS of the scratch scripts NLS/Ibc-test.py:163-164 and
+// NLS/testGNSS.py:139-140, as coded there (the 6 rho v_xx / 10 rho u_xx asymmetry included):
+//   fu = u_t + a v_xx + b rho v + c4 Gv - c3 (u_xxx + 6 rho u_x)
+//   fv = v_t - a u_xx - b rho u - c4 Gu - c3 (v_xxx + 6 rho v_x)
+//   Gv = v_4x + 6v(v_x^2 - u_x^2) + 12 u u_x v_x + 4v(u_x^2 + v_x^2) + p rho v_xx + 6 rho^2 v
+//   Gu = u_4x + 6u(u_x^2 - v_x^2) + 12 v u_x v_x + 4u(u_x^2 + v_x^2) + q rho u_xx + 6 rho^2 u
+// coef = [a, b, c3, c4, p, q] = [0.5, 1, 0.125, 0.0625, 6, 10].
+template <> struct Residual<EQ_LPD> {
+    static constexpr int K = 4, KT = 1;
+    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    {
+        const float *u = D[0], *v = D[1];
+        const float a = c[0], b = c[1], c3 = c[2], c4 = c[3], pp = c[4], qq = c[5];
+        const float rho = u[0] * u[0] + v[0] * v[0];
+        const float Gv = v[4] + 10.0f * v[0] * v[1] * v[1] - 2.0f * v[0] * u[1] * u[1] + 12.0f * u[0] * u[1] * v[1]
+                       + pp * rho * v[2] + 6.0f * rho * rho * v[0];
+        const float Gu = u[4] + 10.0f * u[0] * u[1] * u[1] - 2.0f * u[0] * v[1] * v[1] + 12.0f * v[0] * u[1] * v[1]
+                       + qq * rho * u[2] + 6.0f * rho * rho * u[0];
+        f[0] = T[0][0] + a * v[2] + b * rho * v[0] + c4 * Gv - c3 * (u[3] + 6.0f * rho * u[1]);
+        f[1] = T[1][0] - a * u[2] - b * rho * u[0] - c4 * Gu - c3 * (v[3] + 6.0f * rho * v[1]);
+    }
+    template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
+                                                  const float *fb, A &Db, A &Tb)
+    {
+        const float *u = D[0], *v = D[1];
+        const float a = c[0], b = c[1], c3 = c[2], c4 = c[3], pp = c[4], qq = c[5];
+        const float rho = u[0] * u[0] + v[0] * v[0];
+        const float g0 = fb[0], g1 = fb[1];
+        // partial derivatives of Gv and Gu
+        const float Gv_u0 = 12.0f * u[1] * v[1] + 2.0f * pp * u[0] * v[2] + 24.0f * rho * u[0] * v[0];
+        const float Gv_v0 = 10.0f * v[1] * v[1] - 2.0f * u[1] * u[1] + 2.0f * pp * v[0] * v[2] + 24.0f * rho * v[0] * v[0] + 6.0f * rho * rho;
+        const float Gv_u1 = -4.0f * v[0] * u[1] + 12.0f * u[0] * v[1];
+        const float Gv_v1 = 20.0f * v[0] * v[1] + 12.0f * u[0] * u[1];
+        const float Gu_u0 = 10.0f * u[1] * u[1] - 2.0f * v[1] * v[1] + 2.0f * qq * u[0] * u[2] + 24.0f * rho * u[0] * u[0] + 6.0f * rho * rho;
+        const float Gu_v0 = 12.0f * u[1] * v[1] + 2.0f * qq * v[0] * u[2] + 24.0f * rho * u[0] * v[0];
+        const float Gu_u1 = 20.0f * u[0] * u[1] + 12.0f * v[0] * v[1];
+        const float Gu_v1 = -4.0f * u[0] * v[1] + 12.0f * v[0] * u[1];
+        Tb[0][0] += g0;
+        Tb[1][0] += g1;
+        Db[0][0] += g0 * (2.0f * b * u[0] * v[0] + c4 * Gv_u0 - 12.0f * c3 * u[0] * u[1])
+                  + g1 * (-b * (rho + 2.0f * u[0] * u[0]) - c4 * Gu_u0 - 12.0f * c3 * u[0] * v[1]);
+        Db[1][0] += g0 * (b * (rho + 2.0f * v[0] * v[0]) + c4 * Gv_v0 - 12.0f * c3 * v[0] * u[1])
+                  + g1 * (-2.0f * b * v[0] * u[0] - c4 * Gu_v0 - 12.0f * c3 * v[0] * v[1]);
+        Db[0][1] += g0 * (c4 * Gv_u1 - 6.0f * c3 * rho) + g1 * (-c4 * Gu_u1);
+        Db[1][1] += g0 * (c4 * Gv_v1) + g1 * (-c4 * Gu_v1 - 6.0f * c3 * rho);
+        Db[1][2] += g0 * (a + c4 * pp * rho);
+        Db[0][2] += g1 * (-a - c4 * qq * rho);
+        Db[0][3] -= g0 * c3;
+        Db[1][3] -= g1 * c3;
+        Db[1][4] += g0 * c4;
+        Db[0][4] -= g1 * c4;
     }
 };
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     const int n_lin = d.n_lin;
     const int NH = n_lin - 1;                      // tanh layers
     const int nout = d.nout;
-    const int nf = (EQ == EQ_NONE) ? nout : (EQ == EQ_GNSS ? 2 : 1);
+    const int nf = (EQ == EQ_NONE) ? nout : ((EQ == EQ_GNSS || EQ == EQ_LPD) ? 2 : 1);
     const int P = d.P;
     const int tid = threadIdx.x;
 
@@ -1321,6 +1321,7 @@ int launch_mfma_eq(float *stash, int eq, const KDesc &kd, const CallArgs &a, int
     case EQ_KDV5:    return launch_mfma_w<EQ_KDV5, MODE>(stash, kd, a, grid, st);
     case EQ_CH:      return launch_mfma_w<EQ_CH, MODE>(stash, kd, a, grid, st);
     case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(stash, kd, a, grid, st);
+    case EQ_LPD:     return launch_mfma_w<EQ_LPD, MODE>(stash, kd, a, grid, st);
 #endif
     case EQ_KDV7:    return launch_mfma_w<EQ_KDV7, MODE>(stash, kd, a, grid, st);
 #endif

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
     const ValuSlots sl = valu_slots(d, J);
     const int lane = threadIdx.x & 63;
     const int nout = d.nout;
-    const int nf = (EQ == EQ_NONE) ? nout : (EQ == EQ_GNSS ? 2 : 1);
+    const int nf = (EQ == EQ_NONE) ? nout : ((EQ == EQ_GNSS || EQ == EQ_LPD) ? 2 : 1);
     float lsum[MAXOUT] = {0.0f, 0.0f};
 
 #define SL(slot) S[(long long)(slot) * NT]

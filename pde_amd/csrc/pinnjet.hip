@@ -73,6 +73,7 @@ int eq_orders(int eq, int nout, int *K, int *KT, int *nf)
     case PINN_EQ_KDV7:    *K = 7; *KT = 1; *nf = 1; return nout == 1 ? 0 : -1;
     case PINN_EQ_CH:      *K = 3; *KT = 3; *nf = 1; return nout == 1 ? 0 : -1;
     case PINN_EQ_GNSS:    *K = 3; *KT = 1; *nf = 2; return nout == 2 ? 0 : -1;
+    case PINN_EQ_LPD:     *K = 4; *KT = 1; *nf = 2; return nout == 2 ? 0 : -1;
     default: return -1;
     }
 }
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_residual_from_derivs(KDesc d, const flo
 {
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
     const int nout = d.nout;
-    const int nf = (EQ == EQ_NONE) ? nout : (EQ == EQ_GNSS ? 2 : 1);
+    const int nf = (EQ == EQ_NONE) ? nout : ((EQ == EQ_GNSS || EQ == EQ_LPD) ? 2 : 1);
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         float D[MAXOUT][J], T[MAXOUT][J], f[MAXOUT] = {0.0f, 0.0f};
@@ -178,6 +179,7 @@ int launch_valu_eq(float *jets, int eq, const KDesc &kd, const CallArgs &a, int 
     case PINN_EQ_KDV7:    return launch_valu_t<EQ_KDV7, MODE>(jets, kd, a, grid, st);
     case PINN_EQ_CH:      return launch_valu_t<EQ_CH, MODE>(jets, kd, a, grid, st);
     case PINN_EQ_GNSS:    return launch_valu_t<EQ_GNSS, MODE>(jets, kd, a, grid, st);
+    case PINN_EQ_LPD:     return launch_valu_t<EQ_LPD, MODE>(jets, kd, a, grid, st);
     default: return PINN_ERR_INVALID_DESC;
     }
 }
@@ -438,6 +440,7 @@ int pinn_residual_from_derivs(pinn_handle *h, const float *derivs, int64_t n, fl
     case PINN_EQ_KDV7:    hipLaunchKernelGGL(k_residual_from_derivs<EQ_KDV7>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
     case PINN_EQ_CH:      hipLaunchKernelGGL(k_residual_from_derivs<EQ_CH>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
     case PINN_EQ_GNSS:    hipLaunchKernelGGL(k_residual_from_derivs<EQ_GNSS>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    case PINN_EQ_LPD:     hipLaunchKernelGGL(k_residual_from_derivs<EQ_LPD>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
     default: return PINN_ERR_INVALID_DESC;
     }
     return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;

@@ -133,10 +133,16 @@ class PhysicsInformedNN:
           sw      (x0, u0, tb, Xf, X_prev=None, u_prev=None)              7kdv/sw-73.py:89
           gnss    (x0, u0, v0, tb, Xf[, X_prev, u_prev, v_prev])          NLS/sw-GNSS-adamW.py:89
           bc      (x0, u0, t0, u1, tb, Xf, Xh)           7kdv/bc-7kdv3soliton.py:205
-        numpy float64 arrays in, float32 device tensors kept."""
+        numpy float64 arrays in, float32 device tensors kept.
+        Any variant also takes `earliest_solutions=[(X_ref, h_ref), ...]` (keyword): the Python list of
+        reference-solution terms of NLS/IBCtest.py:211,225, summed into the loss as `loss_s` (:252-258)."""
         v = self.variant
         two = self.equation.nout == 2
         args = list(args)
+        es = kw.pop("earliest_solutions", None)
+        self.earliest_solutions = [(torch.as_tensor(np.asarray(X) if not torch.is_tensor(X) else X).float().to(self.device),
+                                    torch.as_tensor(np.asarray(h) if not torch.is_tensor(h) else h).float().to(self.device))
+                                   for X, h in es] if es else []
         self.x0 = self._t(x0)
         self.u0 = self._t(u0)
         t0 = v.t0
@@ -193,8 +199,9 @@ class PhysicsInformedNN:
         self._tgt0 = torch.cat([self.u0, self.v0], dim=1).contiguous() if two else self.u0
         # size the engines' workspaces once: no closure allocates (or synchronises) afterwards, so the
         # first one is as capturable into a HIP graph as any other (include/pinnjet.h, pinn_reserve)
-        n_data = max(self._X_data.shape[0], self.x1.shape[0] if self.x1 is not None else 0,
-                     self.X_prev.shape[0] if self.X_prev is not None else 0)
+        n_data = max([self._X_data.shape[0], self.x1.shape[0] if self.x1 is not None else 0,
+                      self.X_prev.shape[0] if self.X_prev is not None else 0]
+                     + [X.shape[0] for X, _ in self.earliest_solutions])
         if hasattr(self.engine_f, "reserve"):
             self.engine_f.reserve(self.xf.shape[0])
         if hasattr(self.dnn.engine, "reserve"):
@@ -271,19 +278,19 @@ class PhysicsInformedNN:
         if side is None:
             loss_f = self.loss_f()
 
-        loss1, loss_prev = self._extra_data_terms()
+        loss1, loss_prev, loss_s = self._extra_data_terms()
 
         if side is None:
             loss = loss0 + loss_b + loss_f
             if loss1 is not None:
                 loss = loss + loss1
-            loss = loss + loss_prev
+            loss = loss + loss_prev + loss_s
             loss.backward()
         else:
             loss_d = loss0 + loss_b
             if loss1 is not None:
                 loss_d = loss_d + loss1
-            loss_d = loss_d + loss_prev
+            loss_d = loss_d + loss_prev + loss_s
             loss_d.backward()                  # data-term vjp: concurrent with the kernel on `side`
             side.wait_stream(cur)              # ... whose gradient is added after the data terms' one
             with torch.cuda.stream(side):
@@ -292,28 +299,34 @@ class PhysicsInformedNN:
             if not torch.cuda.is_current_stream_capturing():
                 loss_f.record_stream(cur)
             loss = loss_d.detach() + loss_f.detach()
-        return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev}
+        return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev,
+                "loss_s": loss_s}
 
     def _extra_data_terms(self):
-        """loss1 of the bc classes (7kdv/bc-7kdv3soliton.py:251-253) and loss_prev of the sw classes
-        (7kdv/sw-73.py:132-142): (None | tensor, 0 | tensor) like the reference's locals."""
+        """loss1 of the bc classes (7kdv/bc-7kdv3soliton.py:251-253), loss_prev of the sw classes
+        (7kdv/sw-73.py:132-142) and the list-of-terms loss_s (NLS/IBCtest.py:252-256: mean over ALL elements
+        of square(dnn(X_ref) - h_ref), broadcasting as torch does when h_ref has one column):
+        (None | tensor, 0 | tensor, 0 | tensor) like the reference's locals."""
         v = self.variant
         two = self.equation.nout == 2
         loss1 = None
         loss_prev = 0
+        loss_s = 0
+        for X_ref, h_ref in getattr(self, "earliest_solutions", ()):
+            loss_s = loss_s + torch.mean(torch.square(self.dnn(X_ref) - h_ref))
         if v.style == "bc" and self.u1 is not None:
             out1 = self.dnn(torch.cat([self.x1, self.t1], dim=1))
             loss1 = self._mse(out1, self.u1, self.v1) if two else self._mse(out1, self.u1)
         if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
             outp = self.dnn(self.X_prev)
             loss_prev = self._mse(outp, self.u_prev, self.v_prev) if two else self._mse(outp, self.u_prev)
-        return loss1, loss_prev
+        return loss1, loss_prev, loss_s
 
     def _loss_terms_sharded(self):
         """The closure of a sharded run: every rank evaluates the collocation term on ITS
         shard (value and gradient already scaled by 1/N_global), rank 0 alone evaluates the data terms
-        (IC, boundary, loss1, loss_prev: at most a few thousand points), and ONE all-reduce(SUM) of
-        [flat gradient (P), loss0, loss_b, loss_f, loss1, loss_prev] gives every rank the same bits for
+        (IC, boundary, loss1, loss_prev, loss_s: at most a few thousand points), and ONE all-reduce(SUM) of
+        [flat gradient (P), loss0, loss_b, loss_f, loss1, loss_prev, loss_s] gives every rank the same bits for
         everything an optimizer reads: the float32 sums inside the kernels depend on wave arrival order
         (LDS / memory-side float adds), so nothing a rank computed by itself may reach `.grad` or the
         returned loss.  Adam/AdamW (elementwise) and pde_amd.lbfgs.LBFGS (fixed-order reductions) then
@@ -328,26 +341,30 @@ class PhysicsInformedNN:
             loss_f = _ResidualLossFn.apply(self.dnn, self.engine_f, self.xf, self.tf, self.n_f_global, None, leaf)
             zero = torch.zeros((), dtype=torch.float32, device=self.device)
             loss0 = loss_b = zero
-            loss1, loss_prev = None, 0
+            loss1, loss_prev, loss_s = None, 0, 0
             if dist.get_rank(self.group) == 0:
                 n0, nb = self.x0.shape[0], self.x_lb.shape[0]
                 loss0, loss_b = _DataLossFn.apply(self.dnn, self._X_data, self._tgt0, n0, nb, v.bc == "dirichlet", leaf)
-                loss1, loss_prev = self._extra_data_terms()
+                loss1, loss_prev, loss_s = self._extra_data_terms()
             has1 = v.style == "bc" and self.u1 is not None
             hasp = v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0
+            hass = bool(getattr(self, "earliest_solutions", ()))
             local = loss0 + loss_b + loss_f
             if loss1 is not None:
                 local = local + loss1
             if torch.is_tensor(loss_prev):
                 local = local + loss_prev
+            if torch.is_tensor(loss_s):
+                local = local + loss_s
             g, = torch.autograd.grad(local, leaf)
         finally:
             self.dnn.end_collect()
-        buf = torch.empty(P + 5, dtype=torch.float32, device=self.device)
+        buf = torch.empty(P + 6, dtype=torch.float32, device=self.device)
         buf[:P] = g
         buf[P:] = torch.stack([loss0.detach(), loss_b.detach(), loss_f.detach(),
                                loss1.detach() if loss1 is not None else zero,
-                               loss_prev.detach() if torch.is_tensor(loss_prev) else zero])
+                               loss_prev.detach() if torch.is_tensor(loss_prev) else zero,
+                               loss_s.detach() if torch.is_tensor(loss_s) else zero])
         all_reduce_sum(buf, self.group)
         self.dnn.distribute_flat_grad(buf[:P])
         t = buf[P:]
@@ -356,8 +373,10 @@ class PhysicsInformedNN:
             loss = loss + t[3]
         if hasp:
             loss = loss + t[4]
+        if hass:
+            loss = loss + t[5]
         return {"loss": loss, "loss0": t[0], "loss_b": t[1], "loss_f": t[2], "loss1": t[3] if has1 else None,
-                "loss_prev": t[4] if hasp else 0}
+                "loss_prev": t[4] if hasp else 0, "loss_s": t[5] if hass else 0}
 
     def check_replicas(self):
         """Sharded runs keep the weights identical on every rank WITHOUT a broadcast: every rank applies
@@ -396,6 +415,8 @@ class PhysicsInformedNN:
         else:
             message = 'Iter: %d, Loss: %.5e, Loss_0: %.5e, Loss_b: %.5e, Loss_f: %.5e' % (
                 self.iter, loss.item(), loss0.item(), loss_b.item(), loss_f.item())
+        if torch.is_tensor(terms.get("loss_s", 0)):       # NLS/IBCtest.py:262-263
+            message += ', Loss_s: %.5e' % terms["loss_s"].item()
         if self.logfilename is not None:
             self.writer.write(message)
         if self._is_rank0():

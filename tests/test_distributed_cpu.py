@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -21,6 +22,11 @@ def _free_port():
     return port
 
 
+# golden case -> (drop-in class, feed kind): a one-output PI class, and a two-output class with the
+# list-of-terms loss_s (NLS/IBCtest.py:252-258) that only rank 0 evaluates
+CASES = {"kdv5_xavier": ("5kdv/PI-51.py", "pi"), "nls_ibc_xavier": ("NLS/sw-PINN-rogue.py", "gnss_es")}
+
+
 def _worker(rank, world, port, name, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,10 +36,11 @@ def _worker(rank, world, port, name, out):
     from pde_amd import scripts
     from test_host_logic import feed, flat_grad, load_theta
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    cls = install(scripts.kdv5_1soliton.PI.PhysicsInformedNN)
+    script, kind = CASES[name]
+    cls = install(scripts.for_script(script).PhysicsInformedNN)
     m = cls(g["layers"].tolist(), g["lb"], g["ub"], process_group=dist.group.WORLD)
     load_theta(m, g["theta"])
-    feed(m, g, "pi")
+    feed(m, g, kind)
     assert m.n_f_global == len(g["x"])
     n_local = m.xf.shape[0]
     m.iter = 1
@@ -64,8 +71,8 @@ def _worker(rank, world, port, name, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_matches_single_process():
-    name = "kdv5_xavier"
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_two_rank_sharding_matches_single_process(name):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()

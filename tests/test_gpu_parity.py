@@ -184,12 +184,13 @@ def test_ragged_sizes_against_oracle(name, kname, kernel):
     ("kdv7_3sol", 64, 5), ("kdv7_3sol", 64, 6),                               # the 6 x 64 net of 7kdv/bc-7kdv3soliton.py:366 (global-slab accumulation)
     ("gnss", 100, 1), ("gnss", 100, 2), ("gnss", 100, 4), ("gnss", 50, 5), ("burgers", 100, 3),
     ("burgers", 20, 1), ("burgers", 20, 8), ("kdv5", 20, 3),                 # width 20 = one MFMA tile + 4 tail neurons
+    ("lpd", 100, 4), ("lpd", 64, 3), ("lpd", 20, 2),                          # 4th-order two-output residual (J = 6)
 ])
 def test_mfma_depths_against_oracle(eq, width, depth):
     """The MFMA kernels treat the first and the last tanh layer specially (z recomputed / z kept in
     registers): nets where these coincide or touch, both workgroup shapes (widths <= 64 and 100),
     seeded xavier weights, vs the fp64 oracle.  Tolerance 1e-5 (1e-4 for the 7th-order case)."""
-    nout = 2 if eq == "gnss" else 1
+    nout = 2 if eq in ("gnss", "lpd") else 1
     layers = [2] + [width] * depth + [nout]
     lb, ub = np.array([-5.0, -1.0]), np.array([5.0, 1.0])
     rng = np.random.default_rng(width * 10 + depth)
@@ -332,6 +333,8 @@ def _load_theta(model, theta):
     ("gnss_w100_ckpt", scripts.gnss.sw.PhysicsInformedNN, "gnss_sw"),
     ("gnss_bc_xavier", scripts.gnss.bc.bcPhysicsInformedNN, "gnss_bc"),
     ("nls_w100_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_sw"),
+    ("lpd_w50_xavier", scripts.lpd.bc.bcPhysicsInformedNN, "gnss_bc"),       # 4th-order residual id, NLS/Ibc-test.py
+    ("nls_ibc_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_es"),         # loss_s list of terms, NLS/IBCtest.py:252-258
 ])
 def test_class_backward_matches_reference(name, cls, kind):
     """The drop-in class on the GPU vs the reference's own backward() (fp64 golden)."""

@@ -52,6 +52,8 @@ CASES = [
     ("gnss_w100_ckpt", scripts.gnss.sw.PhysicsInformedNN, "gnss_sw"),
     ("gnss_bc_xavier", scripts.gnss.bc.bcPhysicsInformedNN, "gnss_bc"),      # two-output bc class, NLS/bc-GNSS-torch.py:222-312
     ("nls_w100_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_sw"),        # plain NLS (c = 0), NLS/sw-PINN-rogue.py
+    ("lpd_w50_xavier", scripts.lpd.bc.bcPhysicsInformedNN, "gnss_bc"),       # 4th-order residual id, NLS/Ibc-test.py:222-313
+    ("nls_ibc_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_es"),         # loss_s over a list of terms, NLS/IBCtest.py:252-258
 ]
 
 
@@ -74,6 +76,9 @@ def feed(model, g, kind):
         model.set_training_data(d["x0"], d["u0"], d["v0"], d["tb"], Xf)
     elif kind == "gnss_sw":
         model.set_training_data(d["x0"], d["u0"], d["v0"], d["tb"], Xf, d["X_prev"], d["u_prev"], d["v_prev"])
+    elif kind == "gnss_es":
+        es = [(d["es_X%d" % i], d["es_h%d" % i]) for i in range(sum(k.startswith("es_X") for k in d))]
+        model.set_training_data(d["x0"], d["u0"], d["v0"], d["tb"], Xf, earliest_solutions=es)
 
 
 @pytest.mark.parametrize("name,cls,kind", CASES)
@@ -89,6 +94,17 @@ def test_backward_matches_reference_backward(name, cls, kind):
     assert abs(loss.item() - g["loss_full64"]) <= max(1e-5, 4 * abs(g["loss_full32"] - g["loss_full64"]) / g["loss_full64"]) * g["loss_full64"]
     assert rel(flat_grad(model), g["grad_full64"]) <= max(1e-5, 4 * ref_gerr)
     assert model.iter == 2
+
+
+def test_loss_s_log_line(capsys):
+    """the log line gains ', Loss_s: %.5e' when reference-solution terms are present (NLS/IBCtest.py:262-263)"""
+    g = np.load(os.path.join(GOLDEN, "nls_ibc_xavier.npz"))
+    model = make_model(g, scripts.nls.sw.PhysicsInformedNN)
+    feed(model, g, "gnss_es")
+    model.iter = 0
+    model.backward()
+    out = capsys.readouterr().out
+    assert re.search(r"Iter: 0, Loss: \S+, Loss0: \S+, Loss_b: \S+, Loss_f: \S+, Loss_prev: \S+, Loss_s: \d\.\d{5}e[-+]\d\d", out), out
 
 
 def test_net_f_is_differentiable_like_the_reference():
@@ -178,7 +194,7 @@ def test_script_literals_match_reference():
             for k in ("lr", "max_eval", "history_size", "tolerance_grad"):
                 assert float(v.lbfgs[k]) == c["lbfgs"][k], (where, k)
             n += 1
-    assert n == 40
+    assert n == 42
 
 
 def test_train_hands_the_script_literals_to_lbfgs():
