@@ -50,7 +50,10 @@ enum {
     PINN_EQ_KDV7 = 3,    /* 7kdv/PI-7kdv3soliton.py:122-132 / PI-7kdv1soliton.py:132  coef[0..7] */
     PINN_EQ_CH = 4,      /* CH/PI-CH-1soliton.py:131-138 (coef[0]=0), CH/bc-CH-1soliton.py:270-278 (coef[0]=2) */
     PINN_EQ_GNSS = 5,    /* NLS/sw-GNSS-adamW.py:159-180   coef[0..2]=a,b,c (c=0: plain NLS)     */
-    PINN_EQ_LPD = 6      /* NLS/Ibc-test.py:163-164, NLS/testGNSS.py:139-140 (4th order)  coef[0..5]=0.5,1,0.125,0.0625,6,10 */
+    PINN_EQ_LPD = 6,     /* NLS/Ibc-test.py:163-164, NLS/testGNSS.py:139-140 (4th order)  coef[0..5]=0.5,1,0.125,0.0625,6,10 */
+    PINN_EQ_NLSREG = 7   /* NLS/sw-test.py:159-189: plain NLS + derivative regulariser; coef[0..2]=a,b,lambda(1e-9).
+                            THREE residual rows (pinn_nf = 3): fu, fv and f2 = sqrt(lambda * sum of the six squared
+                            derivatives :173-180), so sum_c mean(f_c^2) = loss_f + reg_term                        */
 };
 
 /* kernel selection.  The FP32-MFMA kernels are instantiated for nets whose hidden layers all have

@@ -98,9 +98,23 @@ def eval_case(mod, cls_name, layers, lb, ub, ckpt, seed, eq, K, KT, pts, extra, 
             p.grad = None
         f = model.net_f(x, t)
         fs = list(f) if isinstance(f, tuple) else [f]
+        reg = None
+        if eq == "nls_reg":      # NLS/sw-test.py:189 returns (fu, fv, reg_term); backward() adds reg_term to the loss (:147)
+            reg = fs.pop()
         loss_f = sum(torch.mean(torch.square(fi)) for fi in fs)
+        if reg is not None:
+            loss_f = loss_f + reg
         loss_f.backward()
         out["f" + tag] = np.concatenate([fi.detach().numpy() for fi in fs], axis=1)
+        if reg is not None:
+            # the build carries the regulariser as a third residual row f2 with mean(f2^2) = reg_term; its golden
+            # column is formed here from the reference's derivatives (columns 1, 2 = u_x, u_xx; 3 = u_t) and checked
+            # against the reference's own reg_term
+            dd = der[:, :, 1:4]
+            f2 = np.sqrt(1e-9 * np.sum(dd * dd, axis=(1, 2)))
+            assert abs(np.mean(f2 * f2) - reg.item()) <= 1e-5 * reg.item(), (np.mean(f2 * f2), reg.item())
+            out["f" + tag] = np.concatenate([out["f" + tag], f2[:, None].astype(out["f" + tag].dtype)], axis=1)
+            out["reg_term" + tag] = np.array(reg.item())
         out["loss_f" + tag] = np.array(loss_f.item())
         out["grad_f" + tag] = flat_grad(model)
         # (3) the reference's full backward() with its data terms
@@ -330,6 +344,19 @@ def main():
     cases.append(("nls_ibc_xavier", "nls", L502, lb, ub,
                   eval_case(mibc, "IbcPhysicsInformedNN", L502, lb, ub, None, 9753, "gnss", 3, 1, pts, ex),
                   "NLS/IBCtest.py IbcPhysicsInformedNN (loss_s over a list of (X_ref, h_ref)) + xavier(manual_seed 9753)"))
+
+    # ---- plain NLS + derivative regulariser, NLS/sw-test.py:159-189 (reg_term added to the loss, :147) ----------
+    mreg = load_script("NLS/sw-test.py")
+    lb, ub = np.array([-5.0, 0.0]), np.array([5.0, 1.0])
+    pts = sample_points(lb, ub, N_PTS, rng)
+    ex = data_terms(rng, lb, ub, 0.0, 2)
+    Xp = sample_points(lb, ub, 20, rng)
+    ex["X_prev"] = Xp
+    ex["u_prev"] = (0.5 * np.cos(Xp[:, 0:1])).astype(np.float32)
+    ex["v_prev"] = (0.25 * np.sin(Xp[:, 1:2])).astype(np.float32)
+    cases.append(("nls_reg_xavier", "nls_reg", L100, lb, ub,
+                  eval_case(mreg, "PhysicsInformedNN", L100, lb, ub, None, 1593, "nls_reg", 2, 1, pts, ex),
+                  "NLS/sw-test.py (plain NLS + 1e-9 derivative regulariser) + xavier(manual_seed 1593)"))
 
     only = os.environ.get("GEN_GOLDEN_ONLY")          # e.g. "gnss_bc_xavier,nls_w100_xavier": write just these
     for name, eq, layers, lb, ub, arrs, src in cases:

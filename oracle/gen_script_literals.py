@@ -19,7 +19,7 @@ SCRIPTS = sorted(
     + glob.glob(os.path.join(REF, "CH", "*.py"))
     + [os.path.join(REF, "NLS", f) for f in ("PI-GNSS-torch.py", "bc-GNSS-torch.py", "sw-GNSS.py", "sw-GNSS-adamW.py",
                                               "sw-PINN-rogue.py",
-                                              "Ibc-test.py")]       # scratch copy kept for its 4th-order residual id
+                                              "Ibc-test.py", "sw-test.py")]   # scratch copies kept for their residual ids (4th order; regulariser)
     + [os.path.join(REF, "Burgers", "Burgers_equation(PINN).py")])
 
 
@@ -40,8 +40,11 @@ def parse_class(name, start, body):
             arg = m.group(1).strip()
             d["t0"] = "argument" if arg == "t0" else num(arg)
             d["t0_line"] = no
-        if re.match(r"\s*self\.t0 = torch\.tensor\(0\*x0\)", ln):
+        if re.match(r"\s*self\.t0 = torch\.tensor\(0\*x0\)", ln) or re.match(r"\s*self\.t0 = torch\.zeros_like\(self\.x0", ln):
             d["t0"], d["t0_line"] = 0.0, no
+        m = re.match(r"\s*lambda_reg = ([0-9.e+-]+)", ln)
+        if m:
+            d["lambda_reg"], d["lambda_reg_line"] = num(m.group(1)), no
         m = re.match(r"\s*loss_b = (.*)", ln)
         if m and "bc_form" not in d:
             d["bc_form"] = "periodic" if "u_lb_pred - u_ub_pred" in m.group(1) else "dirichlet"
@@ -83,6 +86,8 @@ def parse_class(name, start, body):
             else:
                 eq = "unknown"
             d["equation"], d["equation_line"] = eq, no
+    if d.get("equation") == "nls" and "lambda_reg" in d:
+        d["equation"] = "nls_reg"        # plain NLS body + the derivative regulariser added to the loss
     return d
 
 

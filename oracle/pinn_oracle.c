@@ -31,6 +31,7 @@ int orc_orders(const orc_desc *d, int *K, int *KT, int *nf)
     case ORC_EQ_CH:      *K = 3; *KT = 3; *nf = 1; break;
     case ORC_EQ_GNSS:    *K = 3; *KT = 1; *nf = 2; if (nout != 2) return -1; break;
     case ORC_EQ_LPD:     *K = 4; *KT = 1; *nf = 2; if (nout != 2) return -1; break;
+    case ORC_EQ_NLSREG:  *K = 2; *KT = 1; *nf = 3; if (nout != 2) return -1; break;
     default: return -1;
     }
     return 0;
@@ -39,15 +40,19 @@ int orc_orders(const orc_desc *d, int *K, int *KT, int *nf)
 #define REAL float
 #define SFX(n) n##_f32
 #define TANH tanhf
+#define SQRT_ sqrtf
 #include "pinn_oracle_impl.h"
 #undef REAL
 #undef SFX
 #undef TANH
+#undef SQRT_
 
 #define REAL double
 #define SFX(n) n##_f64
 #define TANH tanh
+#define SQRT_ sqrt
 #include "pinn_oracle_impl.h"
 #undef REAL
 #undef SFX
 #undef TANH
+#undef SQRT_

@@ -5,6 +5,7 @@
 #define ORC_MAX_LAYERS 16
 #define ORC_MAXJ 12
 #define ORC_MAXOUT 2
+#define ORC_MAXF 3     /* residual rows per point: two outputs + the penalty row of ORC_EQ_NLSREG */
 
 enum {
     ORC_EQ_NONE = 0,    /* plain net_u, no derivatives                                  */
@@ -14,7 +15,8 @@ enum {
                                        1-soliton 140,70,280,70,70,42,14,1                */
     ORC_EQ_CH = 4,      /* coef[0] = kappa (0 for PI script, 2 for the bc script)        */
     ORC_EQ_GNSS = 5,    /* coef[0..2] = a(0.5), b(1), c(0.1; 0 gives plain NLS)          */
-    ORC_EQ_LPD = 6      /* coef[0..5] = a, b, c3, c4, p, q = 0.5, 1, 0.125, 0.0625, 6, 10 */
+    ORC_EQ_LPD = 6,     /* coef[0..5] = a, b, c3, c4, p, q = 0.5, 1, 0.125, 0.0625, 6, 10 */
+    ORC_EQ_NLSREG = 7   /* coef[0..2] = a, b, lambda (1e-9); three residual rows, NLS/sw-test.py:159-189 */
 };
 
 typedef struct {

@@ -210,6 +210,28 @@ static void SFX(residual)(const orc_desc *d, int K, int KT,
             Db[0][4] += g1 * (-c4);
         }
     } break;
+    case ORC_EQ_NLSREG: { /* NLS/sw-test.py:159-189: fu, fv of the plain NLS and, as a third row,
+                             f2 = sqrt(lambda (u_x^2 + u_xx^2 + u_t^2 + v_x^2 + v_xx^2 + v_t^2)): mean(f2^2) is the script's
+                             reg_term (:173-180), which it adds to the loss (:147) */
+        const REAL *v = D[1];
+        REAL rho = u[0] * u[0] + v[0] * v[0];
+        REAL S = u[1] * u[1] + u[2] * u[2] + T[0][0] * T[0][0] + v[1] * v[1] + v[2] * v[2] + T[1][0] * T[1][0];
+        f[0] = T[0][0] + c[0] * v[2] + c[1] * rho * v[0];
+        f[1] = T[1][0] - c[0] * u[2] - c[1] * rho * u[0];
+        f[2] = SQRT_(c[2] * S);
+        if (fb) {
+            REAL g0 = fb[0], g1 = fb[1];
+            REAL r = f[2] > 0 ? fb[2] * c[2] / f[2] : (REAL)0;
+            Tb[0][0] += g0 + r * T[0][0];
+            Tb[1][0] += g1 + r * T[1][0];
+            Db[1][2] += g0 * c[0] + r * v[2];
+            Db[0][2] += -g1 * c[0] + r * u[2];
+            Db[0][1] += r * u[1];
+            Db[1][1] += r * v[1];
+            Db[0][0] += c[1] * (g0 * (REAL)2 * u[0] * v[0] - g1 * (rho + (REAL)2 * u[0] * u[0]));
+            Db[1][0] += c[1] * (g0 * (rho + (REAL)2 * v[0] * v[0]) - g1 * (REAL)2 * u[0] * v[0]);
+        }
+    } break;
     default: break;
     }
 }
@@ -365,7 +387,7 @@ int SFX(orc_forward)(const orc_desc *d, const REAL *theta, const REAL *x, const 
     {
         SFX(orc_work) wk; REAL *zb, *ab;
         SFX(orc_alloc_work)(d, J, &wk, &zb, &ab);
-        REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXOUT];
+        REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXF];
 #pragma omp for schedule(static)
         for (long p = 0; p < n; ++p) {
             SFX(point_forward)(d, K, KT, theta, x[p], t[p], &wk, D, T);
@@ -390,7 +412,7 @@ int SFX(orc_residual_derivs)(const orc_desc *d, const REAL *derivs, long n, REAL
     if (orc_orders(d, &K, &KT, &nf)) return -1;
     const int J = K + 1 + KT, nout = d->widths[d->n_lin];
     for (long p = 0; p < n; ++p) {
-        REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXOUT];
+        REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXF];
         for (int o = 0; o < nout; ++o) {
             for (int k = 0; k <= K; ++k) D[o][k] = derivs[((size_t)p * nout + o) * J + k];
             for (int k = 0; k < KT; ++k) T[o][k] = derivs[((size_t)p * nout + o) * J + K + 1 + k];
@@ -418,8 +440,8 @@ int SFX(orc_loss_grad)(const orc_desc *d, const REAL *theta, const REAL *x, cons
         SFX(orc_work) wk; REAL *zb, *ab;
         SFX(orc_alloc_work)(d, J, &wk, &zb, &ab);
         REAL *g = (REAL *)calloc(P, sizeof(REAL));
-        double ls[ORC_MAXOUT] = {0};
-        REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXOUT], fb[ORC_MAXOUT];
+        double ls[ORC_MAXF] = {0};
+        REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXF], fb[ORC_MAXF];
         REAL Db[ORC_MAXOUT][ORC_MAXJ], Tb[ORC_MAXOUT][ORC_MAXJ];
 #pragma omp for schedule(static)
         for (long p = 0; p < n; ++p) {

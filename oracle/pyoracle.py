@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libpinn_oracle.so")
 
-EQ_NONE, EQ_BURGERS, EQ_KDV5, EQ_KDV7, EQ_CH, EQ_GNSS, EQ_LPD = range(7)
+EQ_NONE, EQ_BURGERS, EQ_KDV5, EQ_KDV7, EQ_CH, EQ_GNSS, EQ_LPD, EQ_NLSREG = range(8)
 
 # residual coefficient sets, cited from the reference
 COEF = {
@@ -27,9 +27,10 @@ COEF = {
     "gnss": (EQ_GNSS, [0.5, 1.0, 0.1]),                      # NLS/sw-GNSS-adamW.py:178-179
     "nls": (EQ_GNSS, [0.5, 1.0, 0.0]),                       # NLS/sw-PINN-rogue.py:179-180
     "lpd": (EQ_LPD, [0.5, 1.0, 0.125, 0.0625, 6.0, 10.0]),   # NLS/Ibc-test.py:163-164, NLS/testGNSS.py:139-140
+    "nls_reg": (EQ_NLSREG, [0.5, 1.0, 1e-9]),                # NLS/sw-test.py:159-189 (three residual rows)
     "none": (EQ_NONE, []),
 }
-ORDERS = {EQ_NONE: (0, 0), EQ_BURGERS: (2, 1), EQ_KDV5: (5, 1), EQ_KDV7: (7, 1), EQ_CH: (3, 3), EQ_GNSS: (3, 1), EQ_LPD: (4, 1)}
+ORDERS = {EQ_NONE: (0, 0), EQ_BURGERS: (2, 1), EQ_KDV5: (5, 1), EQ_KDV7: (7, 1), EQ_CH: (3, 3), EQ_GNSS: (3, 1), EQ_LPD: (4, 1), EQ_NLSREG: (2, 1)}
 
 
 class _Desc(ctypes.Structure):
@@ -77,7 +78,7 @@ class Oracle:
         self.K, self.KT = ORDERS[eq_id]
         self.J = self.K + 1 + self.KT
         self.nout = self.layers[-1]
-        self.nf = {EQ_NONE: self.nout, EQ_GNSS: 2, EQ_LPD: 2}.get(eq_id, 1)
+        self.nf = {EQ_NONE: self.nout, EQ_GNSS: 2, EQ_LPD: 2, EQ_NLSREG: 3}.get(eq_id, 1)
         d = _Desc()
         d.eq = eq_id
         d.n_lin = len(layers) - 1
@@ -134,7 +135,7 @@ class Oracle:
         theta, x, t = self._prep(dtype, theta, x, t)
         n = x.size
         grad = np.zeros(self.P, dtype=dtype)
-        ls = np.zeros(2, dtype=np.float64)
+        ls = np.zeros(3, dtype=np.float64)
         if gbar is not None:
             gbar = np.ascontiguousarray(np.asarray(gbar, dtype=dtype).reshape(n, self.nf))
             gp = self._p(gbar)

@@ -104,9 +104,10 @@ COEF = {
     "gnss": [0.5, 1.0, 0.1],
     "nls": [0.5, 1.0, 0.0],
     "lpd": [0.5, 1.0, 0.125, 0.0625, 6.0, 10.0],
+    "nls_reg": [0.5, 1.0, 1e-9],
 }
 ORDERS = {"burgers": (2, 1), "kdv5": (5, 1), "kdv7_3sol": (7, 1), "kdv7_1sol": (7, 1),
-          "ch": (3, 3), "ch_bc": (3, 3), "gnss": (3, 1), "nls": (3, 1), "lpd": (4, 1)}
+          "ch": (3, 3), "ch_bc": (3, 3), "gnss": (3, 1), "nls": (3, 1), "lpd": (4, 1), "nls_reg": (2, 1)}
 
 
 def net_f(eq, net, x, t, coef=None):
@@ -142,6 +143,13 @@ def net_f(eq, net, x, t, coef=None):
         fu = ut[0] + a * v[2] + b * rho * v[0] + c4 * Gv - c3 * (u[3] + 6 * rho * u[1])
         fv = vt[0] - a * u[2] - b * rho * u[0] - c4 * Gu - c3 * (v[3] + 6 * rho * v[1])
         return [fu, fv]
+    if eq == "nls_reg":   # NLS/sw-test.py:159-189; third row: mean(f2^2) = the script's reg_term
+        v, vt = d[1]
+        rho = u[0] ** 2 + v[0] ** 2
+        fu = ut[0] + c[0] * v[2] + c[1] * rho * v[0]
+        fv = vt[0] - c[0] * u[2] - c[1] * rho * u[0]
+        f2 = torch.sqrt(c[2] * (u[1] ** 2 + u[2] ** 2 + ut[0] ** 2 + v[1] ** 2 + v[2] ** 2 + vt[0] ** 2))
+        return [fu, fv, f2]
     raise ValueError(eq)
 
 

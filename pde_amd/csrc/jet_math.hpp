@@ -12,18 +12,21 @@
 
 namespace pinn {
 
-enum { EQ_NONE = 0, EQ_BURGERS = 1, EQ_KDV5 = 2, EQ_KDV7 = 3, EQ_CH = 4, EQ_GNSS = 5, EQ_LPD = 6 };
+enum { EQ_NONE = 0, EQ_BURGERS = 1, EQ_KDV5 = 2, EQ_KDV7 = 3, EQ_CH = 4, EQ_GNSS = 5, EQ_LPD = 6, EQ_NLSREG = 7 };
 
 template <int EQ> struct EqTraits;
-template <> struct EqTraits<EQ_NONE>    { static constexpr int K = 0, KT = 0; };
-template <> struct EqTraits<EQ_BURGERS> { static constexpr int K = 2, KT = 1; };
-template <> struct EqTraits<EQ_KDV5>    { static constexpr int K = 5, KT = 1; };
-template <> struct EqTraits<EQ_KDV7>    { static constexpr int K = 7, KT = 1; };
-template <> struct EqTraits<EQ_CH>      { static constexpr int K = 3, KT = 3; };
-template <> struct EqTraits<EQ_GNSS>    { static constexpr int K = 3, KT = 1; };
-template <> struct EqTraits<EQ_LPD>     { static constexpr int K = 4, KT = 1; };
+// NF = residual components per point (0: as many as the net has outputs)
+template <> struct EqTraits<EQ_NONE>    { static constexpr int K = 0, KT = 0, NF = 0; };
+template <> struct EqTraits<EQ_BURGERS> { static constexpr int K = 2, KT = 1, NF = 1; };
+template <> struct EqTraits<EQ_KDV5>    { static constexpr int K = 5, KT = 1, NF = 1; };
+template <> struct EqTraits<EQ_KDV7>    { static constexpr int K = 7, KT = 1, NF = 1; };
+template <> struct EqTraits<EQ_CH>      { static constexpr int K = 3, KT = 3, NF = 1; };
+template <> struct EqTraits<EQ_GNSS>    { static constexpr int K = 3, KT = 1, NF = 2; };
+template <> struct EqTraits<EQ_LPD>     { static constexpr int K = 4, KT = 1, NF = 2; };
+template <> struct EqTraits<EQ_NLSREG>  { static constexpr int K = 2, KT = 1, NF = 3; };
 
 constexpr int MAXOUT = 2;
+constexpr int MAXF = 3;     // residual components per point: two outputs + one penalty row (EQ_NLSREG)
 
 // tanh(x) and w0 = 1 - tanh(x)^2 = sech(x)^2, both to ~1 ulp, branch-free.
 //
@@ -358,6 +361,48 @@ template <> struct Residual<EQ_LPD> {
         Db[1][3] -= g1 * c3;
         Db[1][4] += g0 * c4;
         Db[0][4] -= g1 * c4;
+    }
+};
+
+// Plain NLS with the derivative regulariser of NLS/sw-test.py:159-189:
+//   fu = u_t + a v_xx + b rho v,  fv = v_t - a u_xx - b rho u,
+//   reg_term = lambda (mean u_x^2 + mean u_xx^2 + mean u_t^2 + mean v_x^2 + mean v_xx^2 + mean v_t^2),
+// which the script adds to the loss (:147).  The regulariser rides as a THIRD residual row
+//   f2 = sqrt(lambda (u_x^2 + u_xx^2 + u_t^2 + v_x^2 + v_xx^2 + v_t^2)),   mean(f2^2) = reg_term,
+// so that sum_c mean(f_c^2) is loss_f + reg_term and the same fused kernel serves it.  coef = [a, b, lambda].
+template <> struct Residual<EQ_NLSREG> {
+    static constexpr int K = 2, KT = 1;
+    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    {
+        const float *u = D[0], *v = D[1];
+        const float rho = u[0] * u[0] + v[0] * v[0];
+        f[0] = T[0][0] + c[0] * v[2] + c[1] * rho * v[0];
+        f[1] = T[1][0] - c[0] * u[2] - c[1] * rho * u[0];
+        const float S = u[1] * u[1] + u[2] * u[2] + T[0][0] * T[0][0] + v[1] * v[1] + v[2] * v[2] + T[1][0] * T[1][0];
+        f[2] = sqrtf(c[2] * S);
+    }
+    template <class A> __device__ static void adj(const A &D, const A &T, const float *c, int,
+                                                  const float *fb, A &Db, A &Tb)
+    {
+        const float *u = D[0], *v = D[1];
+        const float rho = u[0] * u[0] + v[0] * v[0];
+        const float g0 = fb[0], g1 = fb[1];
+        Tb[0][0] += g0;
+        Tb[1][0] += g1;
+        Db[1][2] += g0 * c[0];
+        Db[0][2] -= g1 * c[0];
+        Db[0][0] += c[1] * (g0 * 2.0f * u[0] * v[0] - g1 * (rho + 2.0f * u[0] * u[0]));
+        Db[1][0] += c[1] * (g0 * (rho + 2.0f * v[0] * v[0]) - g1 * 2.0f * u[0] * v[0]);
+        // d f2 / d(derivative) = lambda * derivative / f2   (0 where every derivative vanishes)
+        const float S = u[1] * u[1] + u[2] * u[2] + T[0][0] * T[0][0] + v[1] * v[1] + v[2] * v[2] + T[1][0] * T[1][0];
+        const float f2 = sqrtf(c[2] * S);
+        const float r = f2 > 0.0f ? fb[2] * c[2] / f2 : 0.0f;
+        Db[0][1] += r * u[1];
+        Db[0][2] += r * u[2];
+        Tb[0][0] += r * T[0][0];
+        Db[1][1] += r * v[1];
+        Db[1][2] += r * v[2];
+        Tb[1][0] += r * T[1][0];
     }
 };
 

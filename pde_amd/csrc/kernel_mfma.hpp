@@ -128,7 +128,7 @@ template <int W> __host__ __device__ inline MfmaLayout mfma_layout(const KDesc &
     L.gs_hid_stride = W + C::R * W + C::NM * C::R;
     L.gs_out = L.gs_hid + (d.n_lin - 2) * L.gs_hid_stride;
     L.gs_loss = L.gs_out + d.nout * W + d.nout;
-    L.gs_size = ((L.gs_loss + 2 + 3) / 4) * 4;
+    L.gs_size = ((L.gs_loss + MAXF + 3) / 4) * 4;
     off += L.gs_size;
     // The accumulator images are the one big LDS consumer that can move: wide layers never have them, and a
     // deep net whose weights + images + staging would not fit (64 x 5 / 64 x 6, 7kdv/bc-7kdv3soliton.py:366)
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     const int n_lin = d.n_lin;
     const int NH = n_lin - 1;                      // tanh layers
     const int nout = d.nout;
-    const int nf = (EQ == EQ_NONE) ? nout : ((EQ == EQ_GNSS || EQ == EQ_LPD) ? 2 : 1);
+    const int nf = EqTraits<EQ>::NF ? EqTraits<EQ>::NF : (nout < MAXOUT ? nout : MAXOUT);
     const int P = d.P;
     const int tid = threadIdx.x;
 
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     // compact gradient block of Linear layer l < n_lin-1: bias first, then (hidden layers) tail rows / cols
     auto gblock = [&](int l) { return gs + (l == 0 ? 2 * W : L.gs_hid + (l - 1) * L.gs_hid_stride); };
     // the small gradient entries (accumulated with few-lane LDS atomics)
-    float *const slabp = (MODE != MODE_FWD) ? a.slab + (long long)blockIdx.x * (d.P + 2) : nullptr;
+    float *const slabp = (MODE != MODE_FWD) ? a.slab + (long long)blockIdx.x * (d.P + MAXF) : nullptr;
     auto p_b = [&](int l) { return gblock(l); };                      // bias of Linear layer l < n_lin-1: [n]
     auto p_tr = [&](int l) { return gblock(l) + W; };                 // tail rows of Wb_l: [e*W + i]
     auto p_tc = [&](int l) { return gblock(l) + W + R * W; };         // tail columns of Wb_l: [o*TCS + e]
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
 #define PINN_REFRESH() do { lane = lane0; asm volatile("" : "+v"(lane)); p = lane & 15; q = lane >> 4; \
         vnat = (p * 16 + 4 * q) * 4; vyn = (q * 64 + p) * 4; vp = p * 4; } while (0)
     PINN_REFRESH();
-    float lsum[MAXOUT] = {0.0f, 0.0f};
+    float lsum[MAXF] = {0.0f, 0.0f, 0.0f};
 
     // wave-uniform: keep them in SGPRs
     auto uni = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         }
         const long long pt = tile * 16 + p;
         const bool valid = pt < a.n;
-        float f[MAXOUT] = {0.0f, 0.0f};
+        float f[MAXF] = {0.0f, 0.0f, 0.0f};
         Residual<EQ>::eval(D, Tt, d.coef, nout, f);
 
         if (MODE == MODE_FWD) {
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         }
 
         // ---- cotangent of f -> adjoint of the output jets ----
-        float fb[MAXOUT] = {0.0f, 0.0f};
+        float fb[MAXF] = {0.0f, 0.0f, 0.0f};
         for (int c = 0; c < nf; ++c) {
             if (MODE == MODE_LOSS) {
                 fb[c] = valid ? two_scale * f[c] : 0.0f;
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                 if constexpr (GROUPED) {
                     // One row of accumulator tiles (output neurons 16To..16To+15) at a time: NT tiles of
                     // accumulators instead of NT*NT, at the price of re-reading y from the stash NT times.
-                    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + 2) * 4, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + MAXF) * 4, 0x00020000);
                     const int gvoff = (4 * q * W + p) * 4;
                     const int gsoff = d.woff[l] * 4;
 #ifndef PINN_GR
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
                 if (WGLOBAL || L.wglobal) {
                     {
                         // buffer atomics: one per-lane offset VGPR, everything else scalar
-                        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + 2) * 4, 0x00020000);
+                        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(slabp, 0, (d.P + MAXF) * 4, 0x00020000);
                         const int gvoff = (4 * q * W + p) * 4;
                         const int gsoff = d.woff[l] * 4;
 #pragma unroll
@@ -1182,8 +1182,8 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         __syncthreads();
         {
             // parameter order out of the compact block and the accumulator images
-            float *slab = a.slab + (long long)blockIdx.x * (P + 2);
-            for (int i = tid; i < P + 2; i += MFMA_BLOCK) {
+            float *slab = a.slab + (long long)blockIdx.x * (P + MAXF);
+            for (int i = tid; i < P + MAXF; i += MFMA_BLOCK) {
                 float v;
                 if (i >= P) {
                     v = gs[L.gs_loss + (i - P)];
@@ -1322,6 +1322,7 @@ int launch_mfma_eq(float *stash, int eq, const KDesc &kd, const CallArgs &a, int
     case EQ_CH:      return launch_mfma_w<EQ_CH, MODE>(stash, kd, a, grid, st);
     case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(stash, kd, a, grid, st);
     case EQ_LPD:     return launch_mfma_w<EQ_LPD, MODE>(stash, kd, a, grid, st);
+    case EQ_NLSREG:  return launch_mfma_w<EQ_NLSREG, MODE>(stash, kd, a, grid, st);
 #endif
     case EQ_KDV7:    return launch_mfma_w<EQ_KDV7, MODE>(stash, kd, a, grid, st);
 #endif

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
     extern __shared__ float lds_g[];  // [P+2] workgroup partial of (grad, loss sums)
     const int P = d.P;
     if (MODE != MODE_FWD) {
-        for (int i = threadIdx.x; i < P + 2; i += VALU_BLOCK) lds_g[i] = 0.0f;
+        for (int i = threadIdx.x; i < P + MAXF; i += VALU_BLOCK) lds_g[i] = 0.0f;
         __syncthreads();
     }
     const long long NT = (long long)gridDim.x * VALU_BLOCK;
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
     const ValuSlots sl = valu_slots(d, J);
     const int lane = threadIdx.x & 63;
     const int nout = d.nout;
-    const int nf = (EQ == EQ_NONE) ? nout : ((EQ == EQ_GNSS || EQ == EQ_LPD) ? 2 : 1);
-    float lsum[MAXOUT] = {0.0f, 0.0f};
+    const int nf = EqTraits<EQ>::NF ? EqTraits<EQ>::NF : (nout < MAXOUT ? nout : MAXOUT);
+    float lsum[MAXF] = {0.0f, 0.0f, 0.0f};
 
 #define SL(slot) S[(long long)(slot) * NT]
 
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
 #pragma unroll
             for (int k = 0; k < KT; ++k) T[o][k] = (o < nout) ? factorial(k) * SL(zl + o * J + K + 1 + k) : 0.0f;
         }
-        float f[MAXOUT] = {0.0f, 0.0f};
+        float f[MAXF] = {0.0f, 0.0f, 0.0f};
         Residual<EQ>::eval(D, T, d.coef, nout, f);
 
         if (MODE == MODE_FWD) {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
         }
 
         // ---- cotangent of f ----
-        float fb[MAXOUT] = {0.0f, 0.0f};
+        float fb[MAXF] = {0.0f, 0.0f, 0.0f};
         for (int c = 0; c < nf; ++c) {
             if (MODE == MODE_LOSS) {
                 fb[c] = valid ? 2.0f * a.scale * f[c] : 0.0f;
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
             }
         }
         __syncthreads();
-        float *slab = a.slab + (long long)blockIdx.x * (P + 2);
-        for (int i = threadIdx.x; i < P + 2; i += VALU_BLOCK) slab[i] = lds_g[i];
+        float *slab = a.slab + (long long)blockIdx.x * (P + MAXF);
+        for (int i = threadIdx.x; i < P + MAXF; i += VALU_BLOCK) slab[i] = lds_g[i];
     }
 }
 

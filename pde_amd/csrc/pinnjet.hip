@@ -74,6 +74,7 @@ int eq_orders(int eq, int nout, int *K, int *KT, int *nf)
     case PINN_EQ_CH:      *K = 3; *KT = 3; *nf = 1; return nout == 1 ? 0 : -1;
     case PINN_EQ_GNSS:    *K = 3; *KT = 1; *nf = 2; return nout == 2 ? 0 : -1;
     case PINN_EQ_LPD:     *K = 4; *KT = 1; *nf = 2; return nout == 2 ? 0 : -1;
+    case PINN_EQ_NLSREG:  *K = 2; *KT = 1; *nf = 3; return nout == 2 ? 0 : -1;
     default: return -1;
     }
 }
@@ -108,14 +109,14 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(const float *slab, int nbl
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     double s = 0.0;
-    if (i < P + 2) {
+    if (i < P + MAXF) {
         const int per = (nblk + 3) / 4;
         const int b0 = wv * per, b1 = min(nblk, b0 + per);
-        for (int b = b0; b < b1; ++b) s += (double)slab[(size_t)b * (P + 2) + i];
+        for (int b = b0; b < b1; ++b) s += (double)slab[(size_t)b * (P + MAXF) + i];
     }
     part[wv][lane] = s;
     __syncthreads();
-    if (wv == 0 && i < P + 2) {
+    if (wv == 0 && i < P + MAXF) {
         const double tot = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
         if (i < P) {
             if (grad_accum) grad_accum[i] += (float)tot;
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(256) void k_residual_from_derivs(KDesc d, const flo
 {
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
     const int nout = d.nout;
-    const int nf = (EQ == EQ_NONE) ? nout : ((EQ == EQ_GNSS || EQ == EQ_LPD) ? 2 : 1);
+    const int nf = EqTraits<EQ>::NF ? EqTraits<EQ>::NF : (nout < MAXOUT ? nout : MAXOUT);
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
-        float D[MAXOUT][J], T[MAXOUT][J], f[MAXOUT] = {0.0f, 0.0f};
+        float D[MAXOUT][J], T[MAXOUT][J], f[MAXF] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int o = 0; o < MAXOUT; ++o)
 #pragma unroll
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void k_residual_from_derivs(KDesc d, const flo
 template <int EQ, int MODE>
 int launch_valu_t(float *jets, const KDesc &kd, const CallArgs &a, int grid, hipStream_t st)
 {
-    const size_t lds = (MODE == MODE_FWD) ? 0 : (size_t)(kd.P + 2) * sizeof(float);
+    const size_t lds = (MODE == MODE_FWD) ? 0 : (size_t)(kd.P + MAXF) * sizeof(float);
     auto kern = k_valu<EQ, MODE>;
     if (lds > 48 * 1024) {
         if (lds > 160 * 1024) return PINN_ERR_UNSUPPORTED;
@@ -180,6 +181,7 @@ int launch_valu_eq(float *jets, int eq, const KDesc &kd, const CallArgs &a, int 
     case PINN_EQ_CH:      return launch_valu_t<EQ_CH, MODE>(jets, kd, a, grid, st);
     case PINN_EQ_GNSS:    return launch_valu_t<EQ_GNSS, MODE>(jets, kd, a, grid, st);
     case PINN_EQ_LPD:     return launch_valu_t<EQ_LPD, MODE>(jets, kd, a, grid, st);
+    case PINN_EQ_NLSREG:  return launch_valu_t<EQ_NLSREG, MODE>(jets, kd, a, grid, st);
     default: return PINN_ERR_INVALID_DESC;
     }
 }
@@ -200,7 +202,7 @@ int call_need(const pinn_handle *h, int eq, int mode, long long n, Need *nd)
     const int J = K + 1 + KT;
     nd->nf = nf;
     nd->zero_slab = false;
-    nd->slab_per_wg = (mode != MODE_FWD) ? (size_t)(h->kd.P + 2) * sizeof(float) : 0;
+    nd->slab_per_wg = (mode != MODE_FWD) ? (size_t)(h->kd.P + MAXF) * sizeof(float) : 0;
 #ifdef PINN_WITH_MFMA
     if (h->kernel == PINN_KERNEL_MFMA) {
         const long long ntiles = (n + 15) / 16;
@@ -274,7 +276,7 @@ int run(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, float *
     if (rc) return rc;
     if (mode != MODE_FWD) {
         // fixed-order sum of the per-workgroup partials into the caller's buffers
-        const int rb = (h->kd.P + 2 + 63) / 64;
+        const int rb = (h->kd.P + MAXF + 63) / 64;
         hipLaunchKernelGGL(k_reduce_slabs, dim3(rb), dim3(256), 0, st, slab, grid, h->kd.P, grad_accum, loss_accum, nd.nf);
         if (hipGetLastError() != hipSuccess) return PINN_ERR_HIP;
     }
@@ -338,7 +340,7 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     if (kernel == PINN_KERNEL_AUTO) kernel = mfma_ok ? PINN_KERNEL_MFMA : PINN_KERNEL_VALU;
     if (kernel == PINN_KERNEL_MFMA && !mfma_ok) { delete h; return PINN_ERR_UNSUPPORTED; }
     if (kernel != PINN_KERNEL_MFMA && kernel != PINN_KERNEL_VALU) { delete h; return PINN_ERR_INVALID_DESC; }
-    if (kernel == PINN_KERNEL_VALU && (size_t)(kd.P + 2) * sizeof(float) > 160 * 1024) { delete h; return PINN_ERR_UNSUPPORTED; }
+    if (kernel == PINN_KERNEL_VALU && (size_t)(kd.P + MAXF) * sizeof(float) > 160 * 1024) { delete h; return PINN_ERR_UNSUPPORTED; }
     h->kernel = kernel;
     h->mfma_grid = h->n_cu;      // persistent kernels: at most one workgroup per CU
     // set-up work of the no-allocation entry point: this device's address of the static scratch array
@@ -441,6 +443,7 @@ int pinn_residual_from_derivs(pinn_handle *h, const float *derivs, int64_t n, fl
     case PINN_EQ_CH:      hipLaunchKernelGGL(k_residual_from_derivs<EQ_CH>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
     case PINN_EQ_GNSS:    hipLaunchKernelGGL(k_residual_from_derivs<EQ_GNSS>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
     case PINN_EQ_LPD:     hipLaunchKernelGGL(k_residual_from_derivs<EQ_LPD>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
+    case PINN_EQ_NLSREG:  hipLaunchKernelGGL(k_residual_from_derivs<EQ_NLSREG>, grid, block, 0, st, h->kd, derivs, (long long)n, f_out); break;
     default: return PINN_ERR_INVALID_DESC;
     }
     return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;

@@ -10,7 +10,7 @@ from typing import List
 
 import numpy as np
 
-EQ_NONE, EQ_BURGERS, EQ_KDV5, EQ_KDV7, EQ_CH, EQ_GNSS, EQ_LPD = range(7)
+EQ_NONE, EQ_BURGERS, EQ_KDV5, EQ_KDV7, EQ_CH, EQ_GNSS, EQ_LPD, EQ_NLSREG = range(8)
 
 
 @dataclass(frozen=True)
@@ -49,6 +49,8 @@ _add(Equation("ch", EQ_CH, 3, 3, 1, 1, [0.0], "CH/PI-CH-1soliton.py:131-138"))
 _add(Equation("ch_bc", EQ_CH, 3, 3, 1, 1, [2.0], "CH/bc-CH-1soliton.py:140-148,270-278"))
 _add(Equation("gnss", EQ_GNSS, 3, 1, 2, 2, [0.5, 1.0, 0.1], "NLS/sw-GNSS-adamW.py:159-180"))
 _add(Equation("nls", EQ_GNSS, 3, 1, 2, 2, [0.5, 1.0, 0.0], "NLS/sw-PINN-rogue.py:179-180"))
+# plain NLS + the 1e-9 derivative regulariser, which rides as a third residual row (include/pinnjet.h)
+_add(Equation("nls_reg", EQ_NLSREG, 2, 1, 2, 3, [0.5, 1.0, 1e-9], "NLS/sw-test.py:159-189"))
 # 4th-order NLS of the scratch scripts (an optional id of SURVEY 8(a) a7), coefficients as coded there
 _add(Equation("lpd", EQ_LPD, 4, 1, 2, 2, [0.5, 1.0, 0.125, 0.0625, 6.0, 10.0], "NLS/Ibc-test.py:163-164, NLS/testGNSS.py:139-140"))
 

@@ -164,6 +164,7 @@ class _ResidualLossFn(torch.autograd.Function):
             all_reduce_sum(buf, group)
         ctx.net = net
         ctx.grad_flat = buf[:engine.P]
+        engine.last_sums = buf[engine.P:]          # sum_p f_c^2 per residual row (this rank's, unless `group`)
         return buf[engine.P:].sum() / float(n_global)
 
     @staticmethod

@@ -232,6 +232,8 @@ class PhysicsInformedNN:
         f = _ResidualFn.apply(self.dnn, self.engine_f, x, t, self.dnn.grad_leaf())
         if self.equation.nf == 2:
             return f[:, 0:1], f[:, 1:2]
+        if self.equation.nf == 3:      # NLS/sw-test.py:189 returns (fu, fv, reg_term): the third row carries the
+            return f[:, 0:1], f[:, 1:2], torch.mean(torch.square(f[:, 2:3]))      # regulariser (equations.py)
         return f
 
     def loss_f(self):
@@ -300,7 +302,14 @@ class PhysicsInformedNN:
                 loss_f.record_stream(cur)
             loss = loss_d.detach() + loss_f.detach()
         return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev,
-                "loss_s": loss_s}
+                "loss_s": loss_s, "loss_reg": self._reg_share()}
+
+    def _reg_share(self):
+        """This rank's share of the derivative regulariser (NLS/sw-test.py:173-180), which the fused kernel
+        has already summed into loss_f as a third residual row: only the log line needs it apart."""
+        if self.equation.nf != 3:
+            return 0
+        return self.engine_f.last_sums[2].detach() / float(self.n_f_global)
 
     def _extra_data_terms(self):
         """loss1 of the bc classes (7kdv/bc-7kdv3soliton.py:251-253), loss_prev of the sw classes
@@ -326,7 +335,7 @@ class PhysicsInformedNN:
         """The closure of a sharded run: every rank evaluates the collocation term on ITS
         shard (value and gradient already scaled by 1/N_global), rank 0 alone evaluates the data terms
         (IC, boundary, loss1, loss_prev, loss_s: at most a few thousand points), and ONE all-reduce(SUM) of
-        [flat gradient (P), loss0, loss_b, loss_f, loss1, loss_prev, loss_s] gives every rank the same bits for
+        [flat gradient (P), loss0, loss_b, loss_f, loss1, loss_prev, loss_s, reg] gives every rank the same bits for
         everything an optimizer reads: the float32 sums inside the kernels depend on wave arrival order
         (LDS / memory-side float adds), so nothing a rank computed by itself may reach `.grad` or the
         returned loss.  Adam/AdamW (elementwise) and pde_amd.lbfgs.LBFGS (fixed-order reductions) then
@@ -359,12 +368,14 @@ class PhysicsInformedNN:
             g, = torch.autograd.grad(local, leaf)
         finally:
             self.dnn.end_collect()
-        buf = torch.empty(P + 6, dtype=torch.float32, device=self.device)
+        reg = self._reg_share()
+        buf = torch.empty(P + 7, dtype=torch.float32, device=self.device)
         buf[:P] = g
         buf[P:] = torch.stack([loss0.detach(), loss_b.detach(), loss_f.detach(),
                                loss1.detach() if loss1 is not None else zero,
                                loss_prev.detach() if torch.is_tensor(loss_prev) else zero,
-                               loss_s.detach() if torch.is_tensor(loss_s) else zero])
+                               loss_s.detach() if torch.is_tensor(loss_s) else zero,
+                               reg if torch.is_tensor(reg) else zero])
         all_reduce_sum(buf, self.group)
         self.dnn.distribute_flat_grad(buf[:P])
         t = buf[P:]
@@ -376,7 +387,8 @@ class PhysicsInformedNN:
         if hass:
             loss = loss + t[5]
         return {"loss": loss, "loss0": t[0], "loss_b": t[1], "loss_f": t[2], "loss1": t[3] if has1 else None,
-                "loss_prev": t[4] if hasp else 0, "loss_s": t[5] if hass else 0}
+                "loss_prev": t[4] if hasp else 0, "loss_s": t[5] if hass else 0,
+                "loss_reg": t[6] if torch.is_tensor(reg) else 0}
 
     def check_replicas(self):
         """Sharded runs keep the weights identical on every rank WITHOUT a broadcast: every rank applies
@@ -402,6 +414,8 @@ class PhysicsInformedNN:
         self.check_replicas()
         v = self.variant
         loss, loss0, loss_b, loss_f = terms["loss"], terms["loss0"], terms["loss_b"], terms["loss_f"]
+        if torch.is_tensor(terms.get("loss_reg", 0)):     # the script logs Loss_f without its reg_term (sw-test.py:133,151)
+            loss_f = loss_f.detach() - terms["loss_reg"]
         loss1, loss_prev = terms["loss1"], terms["loss_prev"]
         if v.style == "sw" and torch.is_tensor(loss_prev):
             print(f"Overlap loss: {loss_prev.item():.5e}")

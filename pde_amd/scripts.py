@@ -83,6 +83,8 @@ _TABLE = {
     "NLS/bc-GNSS-torch.py": {"PhysicsInformedNN": _pi("gnss", -1.0, _lb(50000, 1e-5)),              # :102 (t0 = -1 here)
                              "bcPhysicsInformedNN": _bc("gnss", _lb(50000, 1e-5))},                 # :245,319,320-329
     "NLS/sw-PINN-rogue.py": {"PhysicsInformedNN": _sw("nls", -1.0, _lb(50000, 1e-9))},              # :103,187,194
+    # scratch copy, kept for its derivative regulariser (lambda_reg = 1e-9, :172-180, added to the loss :147): t0 = 0 (:102)
+    "NLS/sw-test.py": {"PhysicsInformedNN": _sw("nls_reg", 0.0, _lb(50000, 1e-7))},                 # :102,194,195-204
     # scratch copy, kept for its 4th-order (LPD-type) residual id (:163-164; NLS/testGNSS.py:139-140 has the same body)
     "NLS/Ibc-test.py": {"PhysicsInformedNN": _pi("lpd", -5.0, _lb(50000, 1e-5)),                    # :102,171,172-181
                         "bcPhysicsInformedNN": _bc("lpd", _lb(50000, 1e-5))},                       # :245,319,320-329
@@ -131,6 +133,7 @@ camassa_holm_bc = _family(bc="CH/bc-CH-1soliton.py")
 gnss = _family("NLS/PI-GNSS-torch.py", "NLS/sw-GNSS.py", "NLS/sw-GNSS-adamW.py", "NLS/bc-GNSS-torch.py")
 nls = _family(sw="NLS/sw-PINN-rogue.py")
 lpd = _family(bc="NLS/Ibc-test.py")
+nls_reg = _family(sw="NLS/sw-test.py")
 
 # flat aliases used in INTEGRATION.md
 kdv7_3soliton_PI = kdv7_3soliton.PI

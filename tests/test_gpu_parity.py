@@ -137,6 +137,37 @@ def test_loss_and_gradient(name, kname, kernel):
 
 
 @pytest.mark.parametrize("kname,kernel", KINDS)
+def test_regulariser_row_at_a_visible_weight(kname, kernel):
+    """The third residual row of PINN_EQ_NLSREG (NLS/sw-test.py:172-180) with lambda = 0.3 instead of the
+    script's 1e-9, where it is a visible share of the loss: per-row sums and gradient vs the fp64 oracle
+    (itself checked against nested autograd in tests/test_oracle_golden.py), and the vjp mode on all rows."""
+    g = np.load(os.path.join(GOLDEN, "nls_reg_xavier.npz"))
+    coef = [0.5, 1.0, 0.3]
+    eng = NativeEngine(equations.get("nls_reg", coef), g["layers"].tolist(), g["lb"].astype(np.float32),
+                       g["ub"].astype(np.float32), dev(), kernel=kernel)
+    o = Oracle("nls_reg", g["layers"].tolist(), g["lb"], g["ub"], coef=coef)
+    assert eng.nf == 3
+    n = len(g["x"])
+    th64 = g["theta"].astype(np.float64)
+    lref, gref = o.loss_grad(th64, g["x"], g["t"], scale=1.0 / n)
+    assert lref[2] > 0.05 * lref.sum()
+    theta, x, t = cu(g["theta"]), cu(g["x"]), cu(g["t"])
+    ls = torch.zeros(3, device=dev())
+    grad = torch.zeros(eng.P, device=dev())
+    eng.loss_grad(theta, x, t, 1.0 / n, ls, grad)
+    torch.cuda.synchronize()
+    assert rel(ls.cpu().numpy(), lref) < 1e-5
+    assert rel(grad.cpu().numpy(), gref) < 1e-5
+    rng = np.random.default_rng(5)
+    gb = rng.standard_normal((n, 3)).astype(np.float32)
+    g2 = torch.zeros(eng.P, device=dev())
+    eng.residual_vjp(theta, x, t, cu(gb), g2)
+    _, g2ref = o.loss_grad(th64, g["x"], g["t"], gbar=gb.astype(np.float64))
+    torch.cuda.synchronize()
+    assert rel(g2.cpu().numpy(), g2ref) < 1e-5
+
+
+@pytest.mark.parametrize("kname,kernel", KINDS)
 @pytest.mark.parametrize("name", ["kdv7_3sol_ckpt", "gnss_w100_ckpt", "burgers_9x20_xavier", "kdv7_bc_xavier"])
 def test_net_u_forward_and_vjp(name, kname, kernel):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -335,6 +366,7 @@ def _load_theta(model, theta):
     ("nls_w100_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_sw"),
     ("lpd_w50_xavier", scripts.lpd.bc.bcPhysicsInformedNN, "gnss_bc"),       # 4th-order residual id, NLS/Ibc-test.py
     ("nls_ibc_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_es"),         # loss_s list of terms, NLS/IBCtest.py:252-258
+    ("nls_reg_xavier", scripts.nls_reg.sw.PhysicsInformedNN, "gnss_sw"),     # derivative regulariser, NLS/sw-test.py:172-180
 ])
 def test_class_backward_matches_reference(name, cls, kind):
     """The drop-in class on the GPU vs the reference's own backward() (fp64 golden)."""

@@ -12,7 +12,7 @@ import torch
 
 from conftest import GOLDEN, ROOT
 from oracle_engine import install
-from pde_amd import scripts
+from pde_amd import equations, scripts
 from pde_amd._native import LIB_PATH, SYMBOLS
 
 
@@ -54,6 +54,7 @@ CASES = [
     ("nls_w100_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_sw"),        # plain NLS (c = 0), NLS/sw-PINN-rogue.py
     ("lpd_w50_xavier", scripts.lpd.bc.bcPhysicsInformedNN, "gnss_bc"),       # 4th-order residual id, NLS/Ibc-test.py:222-313
     ("nls_ibc_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_es"),         # loss_s over a list of terms, NLS/IBCtest.py:252-258
+    ("nls_reg_xavier", scripts.nls_reg.sw.PhysicsInformedNN, "gnss_sw"),     # derivative regulariser, NLS/sw-test.py:172-180
 ]
 
 
@@ -181,6 +182,8 @@ def test_script_literals_match_reference():
             v = getattr(ns, c["class"]).variant
             where = "%s:%s" % (path, c["class"])
             assert v.equation == c["equation"], where
+            if "lambda_reg" in c:
+                assert equations.get(v.equation).coef[2] == c["lambda_reg"], where
             assert v.bc == c["bc_form"], where
             assert v.optimizer == c["optimizer"], where
             if c["optimizer"] == "adamw":
@@ -194,7 +197,7 @@ def test_script_literals_match_reference():
             for k in ("lr", "max_eval", "history_size", "tolerance_grad"):
                 assert float(v.lbfgs[k]) == c["lbfgs"][k], (where, k)
             n += 1
-    assert n == 42
+    assert n == 43
 
 
 def test_train_hands_the_script_literals_to_lbfgs():

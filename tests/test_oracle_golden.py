@@ -78,6 +78,33 @@ def test_torch_ref_matches_reference(name):
     assert rel(grad.numpy(), g["grad_f64"]) < 1e-9
 
 
+def test_regulariser_row_at_a_visible_weight():
+    """NLS/sw-test.py's lambda_reg = 1e-9 is invisible next to loss_f in float arithmetic, so the third
+    residual row (oracle/pinn_oracle_impl.h, ORC_EQ_NLSREG) is also checked with lambda = 0.3: the fp64
+    oracle vs nested autograd of loss_f + lambda * (six mean-square derivatives), value and gradient."""
+    g = np.load(os.path.join(GOLDEN, "nls_reg_xavier.npz"))
+    coef = [0.5, 1.0, 0.3]
+    net = torch_ref.make_dnn(g["layers"].tolist(), g["lb"], g["ub"], dtype=torch.float64)
+    torch_ref.load_flat_theta(net, g["theta"].astype(np.float64))
+    x = torch.tensor(g["x"].astype(np.float64))[:, None].requires_grad_(True)
+    t = torch.tensor(g["t"].astype(np.float64))[:, None].requires_grad_(True)
+    (u, ut), (v, vt) = torch_ref.derivatives(net, x, t, 2, 1)
+    rho = u[0] ** 2 + v[0] ** 2
+    fu = ut[0] + 0.5 * v[2] + rho * v[0]
+    fv = vt[0] - 0.5 * u[2] - rho * u[0]
+    reg = coef[2] * sum(torch.mean(torch.square(d)) for d in (u[1], u[2], ut[0], v[1], v[2], vt[0]))   # sw-test.py:173-180
+    loss = torch.mean(torch.square(fu)) + torch.mean(torch.square(fv)) + reg
+    loss.backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).numpy()
+    assert reg.item() > 0.05 * loss.item()            # the regulariser is a visible share of this loss
+    o = Oracle("nls_reg", g["layers"].tolist(), g["lb"], g["ub"], coef=coef)
+    n = len(g["x"])
+    ls, grad = o.loss_grad(g["theta"].astype(np.float64), g["x"], g["t"], scale=1.0 / n)
+    assert abs(ls[2] / n - reg.item()) <= 1e-12 * reg.item()
+    assert abs(ls.sum() / n - loss.item()) <= 1e-12 * loss.item()
+    assert rel(grad, gref) < 1e-10
+
+
 def test_known_answer_error_txt(golden_dir):
     """error.txt:101-102: PI 73.pth + 73[-0.5,0.5]201*512.mat -> 3.743270e-01.
     Plain-forward of the C oracle (EQ_NONE) over the full 201x512 grid."""
