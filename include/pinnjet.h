@@ -39,7 +39,7 @@ extern "C" {
 #endif
 
 #define PINN_MAX_LAYERS 16
-#define PINN_MAX_WIDTH 1024   /* any layer; the generic kernels also need 4*(P+2) <= 160 KB of LDS */
+#define PINN_MAX_WIDTH 1024   /* any layer; the generic kernels also need 4*(P+3) <= 160 KB of LDS */
 #define PINN_MAX_OUT 2
 
 /* equation ids: which `net_f` body of the reference is evaluated */
@@ -58,8 +58,10 @@ enum {
 
 /* kernel selection.  The FP32-MFMA kernels are instantiated for nets whose hidden layers all have
  * the SAME width, one of 20, 50, 64, 100 (every width the reference's scripts use), with at least
- * one hidden layer, as long as the weights fit LDS (e.g. not 6 x 64 / 4 x 100 with J >= 7 jets per
- * neuron); every other shape runs the generic VALU kernels, which are ~20x slower. */
+ * one hidden layer, as long as the WEIGHTS fit LDS (the 6 x 64 and 4 x 100 nets of the reference do; five
+ * hidden layers of width 100 do not); every other shape runs the generic VALU kernels, which are ~20x
+ * slower and need the whole gradient (P + 3 floats) in LDS.  A net neither family covers makes pinn_create
+ * return PINN_ERR_UNSUPPORTED. */
 enum {
     PINN_KERNEL_AUTO = 0,    /* the MFMA kernels when an instantiation covers the shape, else VALU     */
     PINN_KERNEL_VALU = 1,    /* generic one-point-per-lane VALU kernels, any widths                    */

@@ -216,12 +216,13 @@ def test_ragged_sizes_against_oracle(name, kname, kernel):
     ("gnss", 100, 1), ("gnss", 100, 2), ("gnss", 100, 4), ("gnss", 50, 5), ("burgers", 100, 3),
     ("burgers", 20, 1), ("burgers", 20, 8), ("kdv5", 20, 3),                 # width 20 = one MFMA tile + 4 tail neurons
     ("lpd", 100, 4), ("lpd", 64, 3), ("lpd", 20, 2),                          # 4th-order two-output residual (J = 6)
+    ("nls_reg", 100, 4), ("nls_reg", 50, 2), ("nls_reg", 64, 1),              # three residual rows (J = 4)
 ])
 def test_mfma_depths_against_oracle(eq, width, depth):
     """The MFMA kernels treat the first and the last tanh layer specially (z recomputed / z kept in
     registers): nets where these coincide or touch, both workgroup shapes (widths <= 64 and 100),
     seeded xavier weights, vs the fp64 oracle.  Tolerance 1e-5 (1e-4 for the 7th-order case)."""
-    nout = 2 if eq in ("gnss", "lpd") else 1
+    nout = equations.get(eq).nout
     layers = [2] + [width] * depth + [nout]
     lb, ub = np.array([-5.0, -1.0]), np.array([5.0, 1.0])
     rng = np.random.default_rng(width * 10 + depth)
@@ -252,6 +253,51 @@ def test_mfma_depths_against_oracle(eq, width, depth):
         assert np.linalg.norm(f.reshape(f64.shape) - f64) <= tol * scale, (n, "f")
         assert rel(ls.cpu().numpy(), lref) < tol, (n, "loss")
         assert rel(grad.cpu().numpy(), gref) < tol, (n, "grad")
+
+
+def _random_cases(k=20):
+    rng = np.random.default_rng(20261111)
+    eqs = ["burgers", "kdv5", "kdv7_3sol", "kdv7_1sol", "ch", "ch_bc", "gnss", "nls", "lpd", "nls_reg", "none"]
+    widths = [20, 50, 64, 100, 33, 7]                     # 33 and 7: no MFMA instantiation -> the VALU kernels
+    out = []
+    for i in range(k):
+        w, depth, n = int(rng.choice(widths)), int(rng.integers(1, 8)), int(rng.integers(1, 3000))
+        if w == 100:
+            depth = min(depth, 4)      # the weights of a net must fit LDS (three 100 x 100 blocks): include/pinnjet.h
+        out.append((eqs[i % len(eqs)], w, depth, n, i))
+    return out
+
+
+@pytest.mark.parametrize("eq,width,depth,n,seed", _random_cases())
+def test_random_shapes_against_oracle(eq, width, depth, n, seed):
+    """Seeded random (equation, width, depth, n) combinations through the automatic kernel choice, vs the fp64
+    oracle: residual, per-row loss sums and gradient (1e-5; 1e-4 for the 7th-order residual)."""
+    e = equations.get(eq)
+    nout = e.nout if eq != "none" else 1 + seed % 2
+    layers = [2] + [width] * depth + [nout]
+    lb, ub = np.array([-4.0, -0.5]), np.array([6.0, 1.5])
+    rng = np.random.default_rng(1000 + seed)
+    theta = []
+    for i in range(len(layers) - 1):
+        fi, fo = layers[i], layers[i + 1]
+        theta.append(rng.standard_normal(fi * fo) * np.sqrt(2.0 / (fi + fo)))
+        theta.append(0.1 * rng.standard_normal(fo))
+    theta = np.concatenate(theta).astype(np.float32)
+    eng = NativeEngine(e, layers, lb.astype(np.float32), ub.astype(np.float32), dev(), kernel=0)
+    o = Oracle(eq, layers, lb, ub)
+    tol = 1e-4 if eq.startswith("kdv7") else 1e-5
+    X = (lb + (ub - lb) * rng.random((n, 2))).astype(np.float32)
+    ls = torch.zeros(eng.nf, device=dev())
+    grad = torch.zeros(eng.P, device=dev())
+    eng.loss_grad(cu(theta), cu(X[:, 0]), cu(X[:, 1]), 1.0 / n, ls, grad)
+    f = eng.residual_fwd(cu(theta), cu(X[:, 0]), cu(X[:, 1])).cpu().numpy()
+    der64, f64 = o.forward(theta.astype(np.float64), X[:, 0], X[:, 1])
+    lref, gref = o.loss_grad(theta.astype(np.float64), X[:, 0], X[:, 1], scale=1.0 / n)
+    torch.cuda.synchronize()
+    scale = max(np.linalg.norm(der64[:, :, j]) for j in range(der64.shape[2]))
+    assert np.linalg.norm(f.reshape(f64.shape) - f64) <= tol * scale
+    assert rel(ls.cpu().numpy(), lref) < tol
+    assert rel(grad.cpu().numpy(), gref) < tol
 
 
 FULL_SIZE = [("kdv7_3sol_ckpt", "valu", KERNEL_VALU, 200_000), ("kdv7_3sol_ckpt", "mfma", KERNEL_MFMA, 1_000_000),
