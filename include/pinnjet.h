@@ -181,6 +181,22 @@ int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const flo
 int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float *loss, float *out4,
                           void *stream);
 
+/* ---- data terms of backward() on the outputs of one net_u batch ------------------------------------------
+ * loss0 / loss_b of the reference's backward() (7kdv/PI-7kdv3soliton.py:99-105; two outputs:
+ * NLS/sw-GNSS-adamW.py:114-129; Dirichlet form: Burgers/Burgers_equation(PINN).py:109), which it forms as a chain
+ * of ~12 small torch kernels each way.  `out` = what pinn_forward wrote for the batch
+ * X = [IC rows (n0) | lower-boundary rows (nb) | upper-boundary rows (nb)], [rows][nout]; tgt0: [n0][nout].
+ *   losses[0] = sum (out - tgt0)^2 / n0 over the IC rows and all columns (nb = 0: any plain mean-square term,
+ *               e.g. loss1 of the bc classes, loss_prev of the sliding-window classes)
+ *   losses[1] = sum (out[lower] - out[upper])^2 / nb (dirichlet == 0) or sum out^2 / nb over both boundary blocks
+ * pinn_data_loss_cotangent writes gbar[rows][nout] = g0 * d losses[0]/d out + gb * d losses[1]/d out (g0, gb: device
+ * scalars, the upstream gradients of the two terms), the argument of pinn_forward_vjp.  One launch each, float64
+ * sums in fixed order; nothing is allocated. */
+int pinn_data_loss(const float *out, const float *tgt0, int32_t n0, int32_t nb, int32_t nout, int32_t dirichlet,
+                   float *losses, void *stream);
+int pinn_data_loss_cotangent(const float *out, const float *tgt0, int32_t n0, int32_t nb, int32_t nout, int32_t dirichlet,
+                             const float *g0, const float *gb, float *gbar, void *stream);
+
 /* ---- Adam / AdamW on the device, one launch per step ------------------------------------
  * Replaces torch.optim.Adam / AdamW(weight_decay=1e-2).step() of the reference's Adam phase
  * (7kdv/PI-7kdv3soliton.py:138,154-157; 7kdv/sw73-adamW.py:170) for parameters held as ONE flat vector:

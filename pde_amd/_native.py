@@ -38,6 +38,7 @@ SYMBOLS = [
     "pinn_create", "pinn_destroy", "pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout",
     "pinn_kernel_kind", "pinn_forward", "pinn_forward_vjp", "pinn_residual_fwd", "pinn_residual_vjp",
     "pinn_loss_grad", "pinn_error_string", "pinn_reserve", "pinn_forward_vjp_static", "pinn_residual_from_derivs", "pinn_adam_step",
+    "pinn_data_loss", "pinn_data_loss_cotangent",
     "pinn_lbfgs_workspace_floats", "pinn_lbfgs_direction", "pinn_lbfgs_eval_stats",
 ]
 
@@ -70,6 +71,9 @@ def load_library():
     lib.pinn_lbfgs_direction.argtypes = [vp, i64, ctypes.c_int32, vp, vp, f32, ctypes.c_int32, vp, vp]
     lib.pinn_lbfgs_eval_stats.argtypes = [vp, vp, i64, vp, vp, vp]
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, ctypes.c_double, ctypes.c_double, f32, f32, ctypes.c_int32, vp]
+    i32 = ctypes.c_int32
+    lib.pinn_data_loss.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.pinn_data_loss_cotangent.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.pinn_error_string.argtypes = [ctypes.c_int]
     lib.pinn_error_string.restype = ctypes.c_char_p
     _lib = lib
@@ -94,6 +98,34 @@ def _split_xt(x, t):
     t = t.reshape(-1).contiguous()
     assert x.numel() == t.numel()
     return x, t, x.data_ptr(), t.data_ptr(), 1, x.numel()
+
+
+def _cur_stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def data_loss(out, tgt0, n0, nb, dirichlet):
+    """[loss0, loss_b] of the reference's backward() from out = net_u([IC | lower | upper rows]) in one launch
+    (include/pinnjet.h, pinn_data_loss).  nb = 0: a plain mean-square term (loss1, loss_prev)."""
+    assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == n0 + 2 * nb
+    tgt0 = tgt0.contiguous()
+    assert tgt0.shape == (n0, out.shape[1]) and tgt0.dtype == torch.float32
+    losses = torch.empty(2, dtype=torch.float32, device=out.device)
+    _check(load_library().pinn_data_loss(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
+                                         losses.data_ptr(), _cur_stream(out)), "pinn_data_loss")
+    return losses
+
+
+def data_loss_cotangent(out, tgt0, n0, nb, dirichlet, g0, gb):
+    """gbar = g0 * d loss0/d out + gb * d loss_b/d out (g0, gb: 0-dim device tensors), one launch."""
+    tgt0 = tgt0.contiguous()
+    g0 = g0.reshape(1).float().contiguous()
+    gb = gb.reshape(1).float().contiguous()
+    gbar = torch.empty_like(out)
+    _check(load_library().pinn_data_loss_cotangent(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
+                                                   g0.data_ptr(), gb.data_ptr(), gbar.data_ptr(), _cur_stream(out)),
+           "pinn_data_loss_cotangent")
+    return gbar
 
 
 class NativeEngine:

@@ -1,0 +1,104 @@
+// The data terms of the reference's backward() on the outputs of one net_u batch, one launch each way.
+//
+// The reference forms loss0 = mean((u0_pred - u0)^2) [+ the same for v], loss_b = mean((u_lb_pred - u_ub_pred)^2)
+// [+ v] (7kdv/PI-7kdv3soliton.py:99-105; two outputs: NLS/sw-GNSS-adamW.py:114-129) or, for Burgers,
+// mean(u_lb_pred^2) + mean(u_ub_pred^2) (Burgers/Burgers_equation(PINN).py:109) as a chain of ~12 small torch
+// kernels forward and as many backward.  At the scripts' sizes (150 data points) that chain, not the arithmetic,
+// is what a closure waits for.  Here the batch is X = [IC rows (n0) | lower-boundary rows (nb) | upper-boundary
+// rows (nb)], `out` = net_u(X) as pinn_forward wrote it ([rows][nout]), and
+//   k_data_loss       : losses[0] = sum_{rows < n0, cols} (out - tgt0)^2 / n0
+//                       losses[1] = sum_{i < nb, cols} (out[n0+i] - out[n0+nb+i])^2 / nb      (periodic)
+//                                   sum_{n0 <= rows, cols} out^2 / nb                        (dirichlet)
+//   k_data_cotangent  : gbar = g0 * d losses[0]/d out + gb * d losses[1]/d out   (g0, gb: device scalars),
+// which pinn_forward_vjp turns into the weight gradient.  Sums in float64, one workgroup, fixed order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pinnjet.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_data_loss(const float *__restrict__ out, const float *__restrict__ tgt0, int n0, int nb,
+                                                    int nout, int dirichlet, float *__restrict__ losses)
+{
+    __shared__ double part[2][4];
+    double s0 = 0.0, sb = 0.0;
+    const int e0 = n0 * nout;
+    for (int i = threadIdx.x; i < e0; i += 256) {
+        const float r = out[i] - tgt0[i];
+        s0 += (double)r * r;
+    }
+    const int eb = (dirichlet ? 2 * nb : nb) * nout;
+    for (int i = threadIdx.x; i < eb; i += 256) {
+        const float r = dirichlet ? out[e0 + i] : out[e0 + i] - out[e0 + nb * nout + i];
+        sb += (double)r * r;
+    }
+    s0 = wave_sum_d(s0);
+    sb = wave_sum_d(sb);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[0][wv] = s0; part[1][wv] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+        const double b = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+        losses[0] = n0 > 0 ? (float)(a / n0) : 0.0f;
+        losses[1] = nb > 0 ? (float)(b / nb) : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_data_cotangent(const float *__restrict__ out, const float *__restrict__ tgt0, int n0,
+                                                         int nb, int nout, int dirichlet, const float *__restrict__ g0,
+                                                         const float *__restrict__ gb, float *__restrict__ gbar)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int e0 = n0 * nout, eb = nb * nout;
+    if (i >= e0 + 2 * eb) return;
+    if (i < e0) {
+        gbar[i] = (out[i] - tgt0[i]) * (g0[0] * (2.0f / (float)n0));
+        return;
+    }
+    const float c = gb[0] * (2.0f / (float)nb);
+    if (dirichlet) {
+        gbar[i] = out[i] * c;
+    } else {
+        const int j = i - e0;                                 // lower rows first, then upper rows
+        const int k = j < eb ? j : j - eb;
+        const float t = (out[e0 + k] - out[e0 + eb + k]) * c;
+        gbar[i] = j < eb ? t : -t;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pinn_data_loss(const float *out, const float *tgt0, int32_t n0, int32_t nb, int32_t nout, int32_t dirichlet,
+                   float *losses, void *stream)
+{
+    if (!out || !losses || (n0 > 0 && !tgt0)) return PINN_ERR_NULL;
+    if (n0 < 0 || nb < 0 || nout < 1 || nout > PINN_MAX_OUT) return PINN_ERR_INVALID_DESC;
+    hipLaunchKernelGGL(k_data_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, out, tgt0, n0, nb, nout, dirichlet, losses);
+    return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+}
+
+int pinn_data_loss_cotangent(const float *out, const float *tgt0, int32_t n0, int32_t nb, int32_t nout, int32_t dirichlet,
+                             const float *g0, const float *gb, float *gbar, void *stream)
+{
+    if (!out || !gbar || !g0 || !gb || (n0 > 0 && !tgt0)) return PINN_ERR_NULL;
+    if (n0 < 0 || nb < 0 || nout < 1 || nout > PINN_MAX_OUT) return PINN_ERR_INVALID_DESC;
+    const long long total = ((long long)n0 + 2LL * nb) * nout;
+    if (total == 0) return PINN_OK;
+    if (total > (1LL << 30)) return PINN_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(k_data_cotangent, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, tgt0, n0,
+                       nb, nout, dirichlet, g0, gb, gbar);
+    return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,5 +1,6 @@
 // C-ABI of the PINN collocation engine (include/pinnjet.h) and kernel dispatch.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <stdlib.h>
@@ -28,6 +29,8 @@ struct pinn_handle {
     float *slab = nullptr;       // per-workgroup partial [grid][P+2]
     size_t slab_bytes = 0;
     int mfma_grid = 0;           // persistent grid of the MFMA kernels (<= n_cu)
+    int spare_cus = 32;          // CUs a small launch leaves free for launches on other streams: one per shader
+                                 // engine of every XCD (with 8 or 16, a 31-workgroup fill still queued behind the launch)
 };
 
 // ---- the scratch of pinn_forward_vjp_static -------------------------------------------------------
@@ -195,6 +198,7 @@ struct Need {
     bool zero_slab;     // wide MFMA layers add into the slab with memory-side atomics: it has to start at zero
 };
 
+
 int call_need(const pinn_handle *h, int eq, int mode, long long n, Need *nd)
 {
     int K, KT, nf;
@@ -208,8 +212,20 @@ int call_need(const pinn_handle *h, int eq, int mode, long long n, Need *nd)
         const long long ntiles = (n + 15) / 16;
         const int waves = mfma_waves(h->kd, J);
         // one workgroup per CU at most; with fewer tiles than that, one tile per workgroup (the kernel deals
-        // tiles to workgroups first, to the waves of a workgroup second)
-        nd->grid = (int)(ntiles < h->mfma_grid ? ntiles : h->mfma_grid);
+        // tiles to workgroups first, to the waves of a workgroup second).  A launch whose tiles all get a wave
+        // of their own anyway (the scripts' N_f <= 20 000) leaves four CUs per XCD free: a training closure runs
+        // its small data-term launches on another stream beside this one, and a workgroup of theirs cannot
+        // share a CU with one of these (LDS) - without a free CU they would queue up behind the whole launch.
+        const int SPARE_CUS = h->spare_cus;
+        int cap = h->mfma_grid;
+        if (cap > 4 * SPARE_CUS && ntiles <= (long long)(cap - SPARE_CUS) * waves) cap -= SPARE_CUS;
+        nd->grid = (int)(ntiles < cap ? ntiles : cap);
+        // ... and the small launches themselves (the IC / boundary batch: a few hundred points) pack four tiles
+        // per workgroup (one per SIMD), so that they fit into those free CUs instead of asking for one CU per tile
+        if (cap > 4 * SPARE_CUS && ntiles <= 8 * SPARE_CUS) {
+            const long long packed = (ntiles + 3) / 4;
+            nd->grid = (int)(packed < SPARE_CUS ? packed : SPARE_CUS);
+        }
         nd->jets_per_wg = (mode != MODE_FWD) ? mfma_stash_floats(h->kd, J) * sizeof(float) * waves : 0;
         nd->zero_slab = (mode != MODE_FWD) && mfma_wglobal(h->kd, J);
         return PINN_OK;
@@ -343,6 +359,10 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     if (kernel == PINN_KERNEL_VALU && (size_t)(kd.P + MAXF) * sizeof(float) > 160 * 1024) { delete h; return PINN_ERR_UNSUPPORTED; }
     h->kernel = kernel;
     h->mfma_grid = h->n_cu;      // persistent kernels: at most one workgroup per CU
+    if (const char *e = getenv("PINN_SPARE_CUS")) {          // development knob
+        const int v = atoi(e);
+        if (v >= 0 && v <= h->n_cu / 4) h->spare_cus = v;
+    }
     // set-up work of the no-allocation entry point: this device's address of the static scratch array
     { const int rc = static_scratch_lookup(h->device); if (rc) { delete h; return rc; } }
     *out = h;

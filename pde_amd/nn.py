@@ -84,33 +84,77 @@ class _DataLossFn(torch.autograd.Function):
     Burgers/Burgers_equation(PINN).py:109) as ONE op over the batch X = [IC points | lower-boundary
     points | upper-boundary points]: one net_u forward, the two mean-square sums, and in backward one
     net_u vjp with the cotangent 2 r / n.  Same values as the chain of torch ops it replaces (the sums
-    run over all columns at once), a dozen fewer kernels and autograd nodes per closure."""
+    run over all columns at once), a dozen fewer kernels and autograd nodes per closure.
+
+    On the GPU the sums and the cotangent are one launch each (pinn_data_loss / pinn_data_loss_cotangent:
+    a closure at the scripts' sizes waits for the LENGTH of this chain, not for its arithmetic); the torch
+    expressions below are what the CPU tests of the host logic run."""
 
     @staticmethod
     def forward(ctx, net, X, tgt0, n0, nb, dirichlet, leaf):
         theta = net.flat_theta()
         out = net.engine.forward(theta, X, None)
+        ctx.net, ctx.X, ctx.out, ctx.tgt0 = net, X, out, tgt0
+        ctx.n0, ctx.nb, ctx.dirichlet = n0, nb, dirichlet
+        if out.is_cuda:
+            from ._native import data_loss
+            losses = data_loss(out, tgt0, n0, nb, dirichlet)
+            return losses[0], losses[1]
         r0 = out[:n0] - tgt0
         rb = out[n0:] if dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
-        ctx.net, ctx.X, ctx.r0, ctx.rb = net, X, r0, rb
-        ctx.n0, ctx.nb, ctx.dirichlet = n0, nb, dirichlet
         return (r0 * r0).sum() / n0, (rb * rb).sum() / nb
 
     @staticmethod
     def backward(ctx, g0, gb):
-        net, n0, nb = ctx.net, ctx.n0, ctx.nb
+        net, n0, nb, out, tgt0 = ctx.net, ctx.n0, ctx.nb, ctx.out, ctx.tgt0
         theta = net.flat_theta()
-        gbar = torch.empty((n0 + 2 * nb, ctx.r0.shape[1]), dtype=torch.float32, device=theta.device)
-        gbar[:n0] = ctx.r0 * (g0 * (2.0 / n0))
-        tb = ctx.rb * (gb * (2.0 / nb))
-        if ctx.dirichlet:
-            gbar[n0:] = tb
+        if out.is_cuda:
+            from ._native import data_loss_cotangent
+            gbar = data_loss_cotangent(out, tgt0, n0, nb, ctx.dirichlet, g0, gb)
         else:
-            gbar[n0:n0 + nb] = tb
-            gbar[n0 + nb:] = -tb
+            r0 = out[:n0] - tgt0
+            rb = out[n0:] if ctx.dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
+            gbar = torch.empty((n0 + 2 * nb, out.shape[1]), dtype=torch.float32, device=theta.device)
+            gbar[:n0] = r0 * (g0 * (2.0 / n0))
+            tb = rb * (gb * (2.0 / nb))
+            if ctx.dirichlet:
+                gbar[n0:] = tb
+            else:
+                gbar[n0:n0 + nb] = tb
+                gbar[n0 + nb:] = -tb
         g = torch.zeros_like(theta)
         net.engine.forward_vjp(theta, ctx.X, None, gbar, g)
         return None, None, None, None, None, None, g
+
+
+class _MseLossFn(torch.autograd.Function):
+    """sum_c mean((net_u(X)[:, c] - tgt[:, c])^2): loss1 of the bc classes (7kdv/bc-7kdv3soliton.py:251-253) and
+    loss_prev of the sliding-window classes (7kdv/sw-73.py:132-142) as one op: forward, one launch for the sum,
+    one for the cotangent, the vjp (the same kernels as _DataLossFn with no boundary rows)."""
+
+    @staticmethod
+    def forward(ctx, net, X, tgt, leaf):
+        theta = net.flat_theta()
+        out = net.engine.forward(theta, X, None)
+        ctx.net, ctx.X, ctx.out, ctx.tgt = net, X, out, tgt
+        if out.is_cuda:
+            from ._native import data_loss
+            return data_loss(out, tgt, out.shape[0], 0, False)[0]
+        r = out - tgt
+        return (r * r).sum() / out.shape[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        net, out, tgt = ctx.net, ctx.out, ctx.tgt
+        theta = net.flat_theta()
+        if out.is_cuda:
+            from ._native import data_loss_cotangent
+            gbar = data_loss_cotangent(out, tgt, out.shape[0], 0, False, g, g)
+        else:
+            gbar = (out - tgt) * (g * (2.0 / out.shape[0]))
+        gt = torch.zeros_like(theta)
+        net.engine.forward_vjp(theta, ctx.X, None, gbar, gt)
+        return None, None, None, gt
 
 
 class _ResidualFn(torch.autograd.Function):

@@ -23,7 +23,7 @@ import torch
 
 from . import equations
 from ._native import KERNEL_AUTO, NativeEngine
-from .nn import NetU, _DataLossFn, _ResidualFn, _ResidualLossFn
+from .nn import NetU, _DataLossFn, _MseLossFn, _ResidualFn, _ResidualLossFn
 
 
 class FileWriter:
@@ -179,6 +179,13 @@ class PhysicsInformedNN:
             else:
                 self.X_prev = None
         self.tb = self._t(tb)
+        # the extra mean-square terms as one (points, targets) pair each
+        if self.u1 is not None:
+            self._X1 = torch.cat([self.x1, self.t1], dim=1).contiguous()
+            self._tgt1 = torch.cat([self.u1, self.v1], dim=1).contiguous() if two else self.u1
+        if self.X_prev is not None:
+            self.X_prev = self.X_prev.contiguous()
+            self._tgt_prev = torch.cat([self.u_prev, self.v_prev], dim=1).contiguous() if two else self.u_prev
         if torch.is_tensor(Xf):
             # collocation points sampled on the device (drivers.lhs_device): no host round trip
             Xf = self._shard(Xf.detach())
@@ -324,11 +331,9 @@ class PhysicsInformedNN:
         for X_ref, h_ref in getattr(self, "earliest_solutions", ()):
             loss_s = loss_s + torch.mean(torch.square(self.dnn(X_ref) - h_ref))
         if v.style == "bc" and self.u1 is not None:
-            out1 = self.dnn(torch.cat([self.x1, self.t1], dim=1))
-            loss1 = self._mse(out1, self.u1, self.v1) if two else self._mse(out1, self.u1)
+            loss1 = _MseLossFn.apply(self.dnn, self._X1, self._tgt1, self.dnn.grad_leaf())
         if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
-            outp = self.dnn(self.X_prev)
-            loss_prev = self._mse(outp, self.u_prev, self.v_prev) if two else self._mse(outp, self.u_prev)
+            loss_prev = _MseLossFn.apply(self.dnn, self.X_prev, self._tgt_prev, self.dnn.grad_leaf())
         return loss1, loss_prev, loss_s
 
     def _loss_terms_sharded(self):

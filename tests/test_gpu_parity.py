@@ -136,6 +136,30 @@ def test_loss_and_gradient(name, kname, kernel):
     assert rel(g2.cpu().numpy(), 0.5 * grad.cpu().numpy().astype(np.float64)) < max(2e-5, 4 * ref_gerr)
 
 
+@pytest.mark.parametrize("n0,nb,nout,dirichlet", [(50, 50, 1, False), (100, 37, 2, False), (256, 100, 1, True), (33, 0, 2, False),
+                                                   (1, 1, 1, False), (5000, 0, 1, False)])
+def test_data_loss_kernels(n0, nb, nout, dirichlet):
+    """pinn_data_loss / pinn_data_loss_cotangent vs the chain of torch expressions they replace (the reference's
+    loss0 / loss_b, 7kdv/PI-7kdv3soliton.py:99-105; Burgers :109), in float64, and vs autograd for the cotangent."""
+    from pde_amd._native import data_loss, data_loss_cotangent
+    gen = torch.Generator(device="cpu").manual_seed(n0 * 7 + nb)
+    out = torch.randn(n0 + 2 * nb, nout, generator=gen)
+    tgt = torch.randn(n0, nout, generator=gen)
+    o64 = out.double().requires_grad_(True)
+    r0 = o64[:n0] - tgt.double()
+    rb = o64[n0:] if dirichlet else o64[n0:n0 + nb] - o64[n0 + nb:]
+    l0 = (r0 * r0).sum() / n0
+    lb = (rb * rb).sum() / nb if nb else torch.zeros((), dtype=torch.float64)
+    g0, gb = 0.7, -1.3
+    (g0 * l0 + gb * lb).backward()
+    losses = data_loss(out.to(dev()), tgt.to(dev()), n0, nb, dirichlet)
+    gbar = data_loss_cotangent(out.to(dev()), tgt.to(dev()), n0, nb, dirichlet, torch.tensor(g0, device=dev()), torch.tensor(gb, device=dev()))
+    torch.cuda.synchronize()
+    assert abs(losses[0].item() - l0.item()) <= 2e-7 * abs(l0.item())
+    assert abs(losses[1].item() - lb.item()) <= 2e-7 * abs(lb.item())
+    assert rel(gbar.cpu().numpy(), o64.grad.numpy()) < 3e-7
+
+
 @pytest.mark.parametrize("kname,kernel", KINDS)
 def test_regulariser_row_at_a_visible_weight(kname, kernel):
     """The third residual row of PINN_EQ_NLSREG (NLS/sw-test.py:172-180) with lambda = 0.3 instead of the

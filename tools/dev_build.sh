@@ -9,7 +9,7 @@ mkdir -p build_dev/$name
 flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DPINN_WITH_MFMA -DPINN_DEV_${WHICH:-KDV7}_ONLY"
 /opt/rocm/bin/hipcc $flags "$@" -save-temps=obj -c pde_amd/csrc/pinnjet.hip -o build_dev/$name/pinnjet.o
 [ -f build_obj/lbfgs.hip.o ] || /opt/rocm/bin/hipcc $flags -c pde_amd/csrc/lbfgs.hip -o build_obj/lbfgs.hip.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build_dev/$name/pinnjet.o build_obj/lbfgs.hip.o build_obj/adam.hip.o -o build_dev/lib_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build_dev/$name/pinnjet.o build_obj/lbfgs.hip.o build_obj/adam.hip.o build_obj/dataloss.hip.o -o build_dev/lib_$name.so
 s=$(ls build_dev/$name/*gfx950*.s | head -1)
 grep -A40 "k_mfmaILi3ELi50ELi2E" $s | grep -m1 -A30 "\.amdhsa_kernel\|; Kernel info" >/dev/null 2>&1 || true
 python3 - "$s" <<'PY'
