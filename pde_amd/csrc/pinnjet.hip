@@ -105,22 +105,34 @@ __global__ __launch_bounds__(256) void k_zero_floats(float *p, long long n)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.0f;
 }
 
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float *slab, int nblk, int P, float *grad_accum,
-                                                      float *loss_accum, int nf)
+// 16 waves per workgroup, each over a 16th of the slabs for 64 consecutive entries (the loads of a wave's loop are
+// independent and issued ahead of the float64 adds; the order of the adds is fixed)
+constexpr int REDUCE_WAVES = 16;
+__global__ __launch_bounds__(64 * REDUCE_WAVES) void k_reduce_slabs(const float *slab, int nblk, int P, float *grad_accum,
+                                                                    float *loss_accum, int nf)
 {
-    __shared__ double part[4][64];
+    __shared__ double part[REDUCE_WAVES][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     double s = 0.0;
     if (i < P + MAXF) {
-        const int per = (nblk + 3) / 4;
+        const int per = (nblk + REDUCE_WAVES - 1) / REDUCE_WAVES;
         const int b0 = wv * per, b1 = min(nblk, b0 + per);
-        for (int b = b0; b < b1; ++b) s += (double)slab[(size_t)b * (P + MAXF) + i];
+        const float *src = slab + i;
+        int b = b0;
+        for (; b + 4 <= b1; b += 4) {
+            const float v0 = src[(size_t)b * (P + MAXF)], v1 = src[(size_t)(b + 1) * (P + MAXF)];
+            const float v2 = src[(size_t)(b + 2) * (P + MAXF)], v3 = src[(size_t)(b + 3) * (P + MAXF)];
+            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        }
+        for (; b < b1; ++b) s += (double)src[(size_t)b * (P + MAXF)];
     }
     part[wv][lane] = s;
     __syncthreads();
     if (wv == 0 && i < P + MAXF) {
-        const double tot = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < REDUCE_WAVES; ++w) tot += part[w][lane];
         if (i < P) {
             if (grad_accum) grad_accum[i] += (float)tot;
         } else if (loss_accum && (i - P) < nf) {
@@ -293,7 +305,7 @@ int run(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, float *
     if (mode != MODE_FWD) {
         // fixed-order sum of the per-workgroup partials into the caller's buffers
         const int rb = (h->kd.P + MAXF + 63) / 64;
-        hipLaunchKernelGGL(k_reduce_slabs, dim3(rb), dim3(256), 0, st, slab, grid, h->kd.P, grad_accum, loss_accum, nd.nf);
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(rb), dim3(64 * REDUCE_WAVES), 0, st, slab, grid, h->kd.P, grad_accum, loss_accum, nd.nf);
         if (hipGetLastError() != hipSuccess) return PINN_ERR_HIP;
     }
     return PINN_OK;

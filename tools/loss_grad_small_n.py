@@ -1,5 +1,6 @@
 """Fused loss+gradient kernel at the scripts' own collocation sizes (N_f = 20 000) and below: time per
-launch vs N and vs the number of workgroups (PINN_MFMA_GRID), 7kdv [2,50x4,1] and GNSS [2,100x4,2]."""
+launch vs N and vs the number of CUs a small launch leaves free (PINN_SPARE_CUS values as arguments; default 32),
+7kdv [2,50x4,1] and GNSS [2,100x4,2]."""
 import os
 import sys
 import time
@@ -18,11 +19,11 @@ for eq, layers, lb, ub in CASES:
     lb, ub = np.array(lb, dtype=np.float32), np.array(ub, dtype=np.float32)
     P = sum(layers[i] * layers[i + 1] + layers[i + 1] for i in range(len(layers) - 1))
     th = torch.randn(P, device=dev) * 0.2
-    for grid in (sys.argv[1:] or ["0"]):
-        if grid != "0":
-            os.environ["PINN_MFMA_GRID"] = grid
+    for grid in (sys.argv[1:] or ["default"]):
+        if grid != "default":
+            os.environ["PINN_SPARE_CUS"] = grid
         else:
-            os.environ.pop("PINN_MFMA_GRID", None)
+            os.environ.pop("PINN_SPARE_CUS", None)
         eng = NativeEngine(equations.get(eq), layers, lb, ub, dev, kernel=2)
         row = []
         for n in (16, 1024, 5000, 20000, 40000, 100000):
@@ -38,4 +39,4 @@ for eq, layers, lb, ub in CASES:
                 eng.loss_grad(th, x, t, 1.0 / n, buf[P:], buf[:P])
             torch.cuda.synchronize()
             row.append("n=%d %.0f us" % (n, (time.perf_counter() - t0) / 30 * 1e6))
-        print(eq, "grid", grid, " | ".join(row), flush=True)
+        print(eq, "spare CUs", grid, " | ".join(row), flush=True)
