@@ -289,17 +289,17 @@ class PhysicsInformedNN:
 
         loss1, loss_prev, loss_s = self._extra_data_terms()
 
+        # (terms that are absent are the reference's Python 0 / None: adding them would be a launch each)
+        extra = [v for v in (loss1, loss_prev, loss_s) if torch.is_tensor(v)]
         if side is None:
             loss = loss0 + loss_b + loss_f
-            if loss1 is not None:
-                loss = loss + loss1
-            loss = loss + loss_prev + loss_s
+            for v in extra:
+                loss = loss + v
             loss.backward()
         else:
             loss_d = loss0 + loss_b
-            if loss1 is not None:
-                loss_d = loss_d + loss1
-            loss_d = loss_d + loss_prev + loss_s
+            for v in extra:
+                loss_d = loss_d + v
             loss_d.backward()                  # data-term vjp: concurrent with the kernel on `side`
             side.wait_stream(cur)              # ... whose gradient is added after the data terms' one
             with torch.cuda.stream(side):
