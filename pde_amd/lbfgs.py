@@ -59,6 +59,8 @@ class LBFGS(torch.optim.Optimizer):
     device).  `flat_params`: the contiguous buffer the parameters are views of, in order
     (NetU.flat_theta()); when omitted the parameters are re-pointed into a new flat buffer."""
 
+    speculate = True      # step(): first line-search evaluation enqueued before the direction's statistics are read
+
     def __init__(self, params, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9,
                  history_size=100, line_search_fn=None, flat_params=None, kernels=None):
         if max_eval is None:
@@ -95,6 +97,7 @@ class LBFGS(torch.optim.Optimizer):
             kernels = NativeLBFGSKernels(n, history_size, dev)
         self._k = kernels
         self._host = torch.empty(8, dtype=torch.float32, pin_memory=True) if dev.type == "cuda" else None
+        self._host2 = torch.empty(16, dtype=torch.float32, pin_memory=True) if dev.type == "cuda" else None
         self._attach_grads()
         st = self.state[self._params[0]]
         st.setdefault("func_evals", 0)
@@ -143,20 +146,38 @@ class LBFGS(torch.optim.Optimizer):
         torch.cuda.current_stream(dev_vec.device).synchronize()
         return self._host[:k].tolist()
 
+    def _read2(self, a, b):
+        """two device vectors, ONE blocking read"""
+        self.host_syncs += 1
+        if self._host is None:
+            return [float(v) for v in a.tolist()], [float(v) for v in b.tolist()]
+        ka, kb = a.numel(), b.numel()
+        self._host2[:ka].copy_(a, non_blocking=True)
+        self._host2[ka:ka + kb].copy_(b, non_blocking=True)
+        torch.cuda.current_stream(a.device).synchronize()
+        v = self._host2[:ka + kb].tolist()
+        return v[:ka], v[ka:]
+
     # ---- one closure evaluation at x0 + t d ------------------------------------------------
-    def _evaluate(self, closure, x0, t):
+    def _evaluate_async(self, closure, x0, t):
+        """enqueue the evaluation; returns (flat gradient copy, device [f, g.d, max|g|, sum|g|]) without reading"""
         torch.add(x0, self._d, alpha=t, out=self._x)
         loss = closure()
         g = self._gather()
-        f, gtd, gmax, _ = self._read(self._k.eval_stats(g, self._d, loss))
-        return _Point(t, f, g.clone(), gtd, gmax)
+        return g.clone(), self._k.eval_stats(g, self._d, loss)
+
+    def _evaluate(self, closure, x0, t):
+        g, ev = self._evaluate_async(closure, x0, t)
+        f, gtd, gmax, _ = self._read(ev)
+        return _Point(t, f, g, gtd, gmax)
 
     def _strong_wolfe(self, closure, x0, t, f0, g0, gtd0, gmax0, d_norm, c1=1e-4, c2=0.9, tolerance_change=1e-9,
-                      max_ls=25):
+                      max_ls=25, first_point=None):
         """Bracketing + zoom phases of the strong-Wolfe search (Nocedal & Wright alg. 3.5/3.6 as
-        arranged in torch.optim.lbfgs._strong_wolfe).  Returns (accepted point, evaluations)."""
+        arranged in torch.optim.lbfgs._strong_wolfe).  Returns (accepted point, evaluations).
+        `first_point`: the evaluation at x0 + t d when step() has already made it."""
         start = _Point(0.0, f0, g0, gtd0, gmax0)
-        new = self._evaluate(closure, x0, t)
+        new = first_point if first_point is not None else self._evaluate(closure, x0, t)
         evals, prev, it = 1, start, 0
         done, bracket = False, None
         while it < max_ls:
@@ -234,14 +255,30 @@ class LBFGS(torch.optim.Optimizer):
             n_iter += 1
             st["n_iter"] += 1
             first = st["n_iter"] == 1
-            gtd, gsum, dmax, _gm, _cnt, _hd, _, _ = self._read(self._k.direction(g, self._d, t, first))
+            dstats = self._k.direction(g, self._d, t, first)
+            spec = x0 = None
+            if wolfe and not first and self.speculate:
+                # From the second iteration on the line search starts at t = lr whatever the direction's
+                # statistics say: that evaluation is enqueued before they are read, and both come back in ONE
+                # blocking read instead of two.  Decisions and evaluation counts are those of the plain order;
+                # only when the search direction turns out not to descend (the break below, i.e. the last
+                # iteration of a run) has one evaluation been made in vain - it is undone and not counted.
+                x0 = self._x.clone()
+                gs, ev = self._evaluate_async(closure, x0, lr)
+                (gtd, gsum, dmax, _gm, _cnt, _hd, _, _), (fs, gtds, gmaxs, _) = self._read2(dstats, ev)
+                spec = _Point(lr, fs, gs, gtds, gmaxs)
+            else:
+                gtd, gsum, dmax, _gm, _cnt, _hd, _, _ = self._read(dstats)
             prev_f = f
             t = min(1.0, 1.0 / gsum) * lr if first else lr
             if gtd > -tol_x:
+                if spec is not None:
+                    self._x.copy_(x0)
                 break
             if wolfe:
-                x0 = self._x.clone()
-                pt, ls_evals = self._strong_wolfe(closure, x0, t, f, g, gtd, gmax, dmax)
+                if x0 is None:
+                    x0 = self._x.clone()
+                pt, ls_evals = self._strong_wolfe(closure, x0, t, f, g, gtd, gmax, dmax, first_point=spec)
                 t, f, g, gmax = pt.t, pt.f, pt.g, pt.gmax
                 torch.add(x0, self._d, alpha=t, out=self._x)
             else:

@@ -66,8 +66,17 @@ def test_same_trajectory_as_torch_lbfgs(kind):
     assert tr_a[-1] < 0.2 * tr_a[0]
     sa, sb = opt_a.state[opt_a._params[0]], opt_b.state[opt_b._params[0]]
     assert sa["func_evals"] == sb["func_evals"] and sa["n_iter"] == sb["n_iter"]
-    # one blocking read per closure evaluation + one per direction
-    assert opt_a.host_syncs == len(tr_a) + sa["n_iter"]
+    # one blocking read per closure evaluation + one for the FIRST direction: from the second iteration on the
+    # direction's statistics come back with the line search's first evaluation (LBFGS.speculate)
+    assert opt_a.host_syncs == len(tr_a) + 1
+    # the plain order (two reads per iteration) makes the same evaluations
+    LBFGS.speculate = False
+    try:
+        tr_c, x_c, opt_c = _run(LBFGS, kind, torch.float32, n_it)
+    finally:
+        LBFGS.speculate = True
+    assert tr_c == tr_a and np.array_equal(x_c, x_a)
+    assert opt_c.host_syncs == len(tr_c) + sa["n_iter"]
 
 
 def test_history_ring_drops_oldest_pair():
