@@ -105,7 +105,14 @@ class LBFGS(torch.optim.Optimizer):
         self.host_syncs = 0
 
     # ---- flat gradient -------------------------------------------------------------------
+    def _intact(self):
+        """every `.grad` is still the view this optimizer attached (identity checks: the per-evaluation host path)"""
+        views = getattr(self, "_views", None)
+        return views is not None and all(p.grad is v for p, v in zip(self._params, views))
+
     def _attach_grads(self):
+        if self._intact():
+            return
         off = 0
         for p in self._params:
             n = p.numel()
@@ -113,6 +120,7 @@ class LBFGS(torch.optim.Optimizer):
             if p.grad is None or p.grad.data_ptr() != want:
                 p.grad = self._g[off:off + n].view(p.shape)
             off += n
+        self._views = [p.grad for p in self._params]
 
     def zero_grad(self, set_to_none=True):
         """Zeroes the flat gradient; `.grad` stay views into it (never set to None)."""
@@ -125,6 +133,8 @@ class LBFGS(torch.optim.Optimizer):
 
     def _gather(self):
         """Flat gradient after a closure; copies only what a foreign zero_grad()/backward re-pointed."""
+        if self._intact():
+            return self._g
         off = 0
         for p in self._params:
             n = p.numel()

@@ -42,13 +42,21 @@ class FusedAdam(torch.optim.Optimizer):
         st["device_state"] = torch.zeros(4, dtype=torch.float64, device=dev)   # step, beta1^t, beta2^t, ticket
         self._attach_grads()
 
+    def _intact(self):
+        """every `.grad` is still the view this optimizer attached (identity checks: the per-step host path)"""
+        views = getattr(self, "_views", None)
+        return views is not None and all(p.grad is v for p, v in zip(self._params, views))
+
     def _attach_grads(self):
+        if self._intact():
+            return
         off = 0
         for p in self._params:
             n = p.numel()
             if p.grad is None or p.grad.data_ptr() != self._g.data_ptr() + 4 * off:
                 p.grad = self._g[off:off + n].view(p.shape)
             off += n
+        self._views = [p.grad for p in self._params]
 
     def zero_grad(self, set_to_none=True):
         """Zeroes the flat gradient; `.grad` stay views into it (one memset instead of ten)."""
@@ -59,6 +67,8 @@ class FusedAdam(torch.optim.Optimizer):
         return self._g
 
     def _gather(self):
+        if self._intact():
+            return
         off = 0
         for p in self._params:
             n = p.numel()
