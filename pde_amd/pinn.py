@@ -249,12 +249,6 @@ class PhysicsInformedNN:
         return _ResidualLossFn.apply(self.dnn, self.engine_f, self.xf, self.tf, self.n_f_global, self.group,
                                      self.dnn.grad_leaf())
 
-    def _mse(self, pred, *targets):
-        s = 0
-        for c, tgt in enumerate(targets):
-            s = s + torch.mean(torch.square(pred[:, c:c + 1] - tgt))
-        return s
-
     def _loss_terms(self, overlap=False):
         """Loss composition of the reference's backward() (:97-120 and variants) + loss.backward().
         Pure device work (no host sync): this is what train() captures into a HIP graph.
