@@ -26,6 +26,21 @@ from ._native import KERNEL_AUTO, NativeEngine
 from .nn import NetU, _DataLossFn, _MseLossFn, _ResidualFn, _ResidualLossFn
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """ONE second stream per GPU for all models of the process: HIP maps streams onto a few hardware queues in
+    turn (GPU_MAX_HW_QUEUES = 4), so the stream of the n-th model of a process can land on the queue of the
+    default stream, where nothing overlaps (measured: the closures of a fourth model ran 25 % slower)."""
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return _SIDE_STREAMS[idx]
+
+
 class FileWriter:
     """reference :63-68 — append one line, re-opening the file each time."""
 
@@ -61,6 +76,10 @@ class PhysicsInformedNN:
     default_device = None            # None -> current CUDA device
     kernel = KERNEL_AUTO
     use_hip_graph = False            # train(): replay the Adam phase from a captured HIP graph (single process)
+    # eager backward(): the collocation kernel on a second stream beside the data-term chain.  None = automatic:
+    # only when that kernel is long enough to pay for the extra host work of two streams (measured at 20 000
+    # points: GNSS width 100 +20 % closures/s, width-50 nets -20 %: their eager closures are host-bound)
+    overlap_streams = None
     hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
     adam_impl = "fused"              # "fused": pde_amd.optim.FusedAdam (one launch per step); "torch": torch.optim.Adam/AdamW
     lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (one launch per direction); "torch": torch.optim.LBFGS
@@ -266,9 +285,7 @@ class PhysicsInformedNN:
         side = cur = None
         if overlap and torch.device(self.device).type == "cuda":
             cur = torch.cuda.current_stream(self.device)
-            if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            side = self._side_stream
+            side = _side_stream(self.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 loss_f = self.loss_f()
@@ -438,7 +455,10 @@ class PhysicsInformedNN:
     def backward(self):
         """Same loss composition as the reference's backward() (:97-120 and variants);
         returns the 0-dim loss with `.grad` accumulated on dnn.parameters()."""
-        terms = self._loss_terms()
+        ov = self.overlap_streams
+        if ov is None:
+            ov = self.xf.shape[0] * self.engine_f.P >= 4e8
+        terms = self._loss_terms(overlap=ov)
         self._log_terms(terms)
         self.iter += 1
         return terms["loss"]

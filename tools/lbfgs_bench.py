@@ -29,7 +29,8 @@ def run(case, impl, n, iters, graph=False):
     c = CASES[case]
     torch.manual_seed(1234)
     base = getattr(scripts, c["family"]).PI.PhysicsInformedNN
-    cls = type("M", (base,), {"lbfgs_impl": impl, "use_hip_graph": graph})
+    ov = {"0": False, "1": True}.get(os.environ.get("PINN_OVERLAP", ""), None)      # eager stream overlap: default automatic
+    cls = type("M", (base,), {"lbfgs_impl": impl, "use_hip_graph": graph, "overlap_streams": ov})
     lb, ub = np.array(c["lb"]), np.array(c["ub"])
     m = cls(c["layers"], lb, ub)
     rng = np.random.default_rng(1)
