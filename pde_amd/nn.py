@@ -58,6 +58,38 @@ def xavier(m):
             torch.nn.init.zeros_(m.bias)
 
 
+def data_loss_values(out, tgt0, n0, nb, dirichlet):
+    """[loss0, loss_b] from out = net_u([IC | lower | upper rows]) (reference :99-105; Burgers :109).  GPU: one
+    launch (pinn_data_loss); CPU tensors (the tests of the host logic): the torch expressions."""
+    if out.is_cuda:
+        from ._native import data_loss
+        return data_loss(out, tgt0, n0, nb, dirichlet)
+    r0 = out[:n0] - tgt0
+    l0 = (r0 * r0).sum() / n0
+    if nb == 0:
+        return torch.stack([l0, torch.zeros_like(l0)])
+    rb = out[n0:] if dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
+    return torch.stack([l0, (rb * rb).sum() / nb])
+
+
+def data_loss_cot(out, tgt0, n0, nb, dirichlet, g0, gb):
+    """g0 * d loss0/d out + gb * d loss_b/d out (g0, gb: 0-dim tensors): the cotangent net_u's vjp takes."""
+    if out.is_cuda:
+        from ._native import data_loss_cotangent
+        return data_loss_cotangent(out, tgt0, n0, nb, dirichlet, g0, gb)
+    gbar = torch.empty_like(out)
+    gbar[:n0] = (out[:n0] - tgt0) * (g0 * (2.0 / n0))
+    if nb > 0:
+        rb = out[n0:] if dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
+        tb = rb * (gb * (2.0 / nb))
+        if dirichlet:
+            gbar[n0:] = tb
+        else:
+            gbar[n0:n0 + nb] = tb
+            gbar[n0 + nb:] = -tb
+    return gbar
+
+
 class _NetUFn(torch.autograd.Function):
     """u = dnn([x,t]) with a theta-gradient.  No gradient flows to the inputs: the
     reference differentiates w.r.t. x,t only inside net_f, which has its own op.
@@ -96,32 +128,14 @@ class _DataLossFn(torch.autograd.Function):
         out = net.engine.forward(theta, X, None)
         ctx.net, ctx.X, ctx.out, ctx.tgt0 = net, X, out, tgt0
         ctx.n0, ctx.nb, ctx.dirichlet = n0, nb, dirichlet
-        if out.is_cuda:
-            from ._native import data_loss
-            losses = data_loss(out, tgt0, n0, nb, dirichlet)
-            return losses[0], losses[1]
-        r0 = out[:n0] - tgt0
-        rb = out[n0:] if dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
-        return (r0 * r0).sum() / n0, (rb * rb).sum() / nb
+        losses = data_loss_values(out, tgt0, n0, nb, dirichlet)
+        return losses[0], losses[1]
 
     @staticmethod
     def backward(ctx, g0, gb):
         net, n0, nb, out, tgt0 = ctx.net, ctx.n0, ctx.nb, ctx.out, ctx.tgt0
         theta = net.flat_theta()
-        if out.is_cuda:
-            from ._native import data_loss_cotangent
-            gbar = data_loss_cotangent(out, tgt0, n0, nb, ctx.dirichlet, g0, gb)
-        else:
-            r0 = out[:n0] - tgt0
-            rb = out[n0:] if ctx.dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
-            gbar = torch.empty((n0 + 2 * nb, out.shape[1]), dtype=torch.float32, device=theta.device)
-            gbar[:n0] = r0 * (g0 * (2.0 / n0))
-            tb = rb * (gb * (2.0 / nb))
-            if ctx.dirichlet:
-                gbar[n0:] = tb
-            else:
-                gbar[n0:n0 + nb] = tb
-                gbar[n0 + nb:] = -tb
+        gbar = data_loss_cot(out, tgt0, n0, nb, ctx.dirichlet, g0, gb)
         g = torch.zeros_like(theta)
         net.engine.forward_vjp(theta, ctx.X, None, gbar, g)
         return None, None, None, None, None, None, g
@@ -137,21 +151,13 @@ class _MseLossFn(torch.autograd.Function):
         theta = net.flat_theta()
         out = net.engine.forward(theta, X, None)
         ctx.net, ctx.X, ctx.out, ctx.tgt = net, X, out, tgt
-        if out.is_cuda:
-            from ._native import data_loss
-            return data_loss(out, tgt, out.shape[0], 0, False)[0]
-        r = out - tgt
-        return (r * r).sum() / out.shape[0]
+        return data_loss_values(out, tgt, out.shape[0], 0, False)[0]
 
     @staticmethod
     def backward(ctx, g):
         net, out, tgt = ctx.net, ctx.out, ctx.tgt
         theta = net.flat_theta()
-        if out.is_cuda:
-            from ._native import data_loss_cotangent
-            gbar = data_loss_cotangent(out, tgt, out.shape[0], 0, False, g, g)
-        else:
-            gbar = (out - tgt) * (g * (2.0 / out.shape[0]))
+        gbar = data_loss_cot(out, tgt, out.shape[0], 0, False, g, g)
         gt = torch.zeros_like(theta)
         net.engine.forward_vjp(theta, ctx.X, None, gbar, gt)
         return None, None, None, gt

@@ -23,7 +23,7 @@ import torch
 
 from . import equations
 from ._native import KERNEL_AUTO, NativeEngine
-from .nn import NetU, _DataLossFn, _MseLossFn, _ResidualFn, _ResidualLossFn
+from .nn import NetU, _DataLossFn, _MseLossFn, _ResidualFn, _ResidualLossFn, data_loss_cot, data_loss_values
 
 
 _SIDE_STREAMS = {}
@@ -80,6 +80,7 @@ class PhysicsInformedNN:
     # only when that kernel is long enough to pay for the extra host work of two streams (measured at 20 000
     # points: GNSS width 100 +20 % closures/s, width-50 nets -20 %: their eager closures are host-bound)
     overlap_streams = None
+    closure_impl = "direct"          # backward(): "direct" (no autograd graph, see _loss_terms_direct) or "autograd"
     hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
     adam_impl = "fused"              # "fused": pde_amd.optim.FusedAdam (one launch per step); "torch": torch.optim.Adam/AdamW
     lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (one launch per direction); "torch": torch.optim.LBFGS
@@ -280,6 +281,8 @@ class PhysicsInformedNN:
         gradient); the returned `loss` is then a detached sum."""
         if self.group is not None:
             return self._loss_terms_sharded()
+        if self.closure_impl == "direct":
+            return self._loss_terms_direct(overlap)
         v = self.variant
         two = self.equation.nout == 2
         side = cur = None
@@ -319,6 +322,77 @@ class PhysicsInformedNN:
             if not torch.cuda.is_current_stream_capturing():
                 loss_f.record_stream(cur)
             loss = loss_d.detach() + loss_f.detach()
+        return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev,
+                "loss_s": loss_s, "loss_reg": self._reg_share()}
+
+    @torch.no_grad()
+    def _loss_terms_direct(self, overlap=False):
+        """The same closure without autograd.  Every term of the reference's loss enters with weight 1 and every
+        native op here knows its own gradient, so `loss.backward()` is: the collocation pass (value + gradient in
+        one kernel), one cotangent launch + one net_u vjp per data term, and ONE add of the flat gradient into
+        `.grad` — no graph, no ones / multiply / accumulate launches, a third of the host time of the autograd
+        form (`closure_impl = "autograd"` selects that one; both are held to the reference's backward() by the
+        same tests).  The list-of-terms loss_s (broadcasting targets) stays on autograd."""
+        v = self.variant
+        dnn, eng = self.dnn, self.dnn.engine
+        theta = dnn.flat_theta()
+        P, nf, N = theta.numel(), self.engine_f.nf, float(self.n_f_global)
+        one = getattr(self, "_one", None)
+        if one is None or one.device != theta.device:
+            one = self._one = torch.ones((), dtype=torch.float32, device=theta.device)
+
+        def collocation():
+            buf = torch.zeros(P + nf, dtype=torch.float32, device=theta.device)
+            self.engine_f.loss_grad(theta, self.xf, self.tf, 1.0 / N, buf[P:], buf[:P])
+            self.engine_f.last_sums = buf[P:]
+            return (buf[P] if nf == 1 else buf[P:].sum()) / N, buf[:P]
+
+        side = cur = None
+        if overlap and torch.device(self.device).type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            side = _side_stream(self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                loss_f, g_f = collocation()
+        g = torch.zeros(P, dtype=torch.float32, device=theta.device)
+        n0, nb = self.x0.shape[0], self.x_lb.shape[0]
+        dirichlet = v.bc == "dirichlet"
+        out = eng.forward(theta, self._X_data, None)
+        losses = data_loss_values(out, self._tgt0, n0, nb, dirichlet)
+        eng.forward_vjp(theta, self._X_data, None, data_loss_cot(out, self._tgt0, n0, nb, dirichlet, one, one), g)
+        loss0, loss_b = losses[0], losses[1]
+        loss = loss0 + loss_b
+
+        def mse_term(X, tgt):
+            o = eng.forward(theta, X, None)
+            val = data_loss_values(o, tgt, o.shape[0], 0, False)[0]
+            eng.forward_vjp(theta, X, None, data_loss_cot(o, tgt, o.shape[0], 0, False, one, one), g)
+            return val
+
+        loss1, loss_prev, loss_s = None, 0, 0
+        if v.style == "bc" and self.u1 is not None:
+            loss1 = mse_term(self._X1, self._tgt1)
+            loss = loss + loss1
+        if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
+            loss_prev = mse_term(self.X_prev, self._tgt_prev)
+            loss = loss + loss_prev
+        if getattr(self, "earliest_solutions", None):
+            with torch.enable_grad():
+                for X_ref, h_ref in self.earliest_solutions:
+                    loss_s = loss_s + torch.mean(torch.square(dnn(X_ref) - h_ref))
+                loss_s.backward()
+            loss_s = loss_s.detach()
+            loss = loss + loss_s
+        if side is None:
+            loss_f, g_f = collocation()
+        else:
+            cur.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():
+                loss_f.record_stream(cur)
+                g_f.record_stream(cur)
+        g.add_(g_f)
+        dnn.distribute_flat_grad(g)
+        loss = loss + loss_f
         return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev,
                 "loss_s": loss_s, "loss_reg": self._reg_share()}
 

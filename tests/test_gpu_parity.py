@@ -438,11 +438,13 @@ def _load_theta(model, theta):
     ("nls_ibc_xavier", scripts.nls.sw.PhysicsInformedNN, "gnss_es"),         # loss_s list of terms, NLS/IBCtest.py:252-258
     ("nls_reg_xavier", scripts.nls_reg.sw.PhysicsInformedNN, "gnss_sw"),     # derivative regulariser, NLS/sw-test.py:172-180
 ])
-def test_class_backward_matches_reference(name, cls, kind):
-    """The drop-in class on the GPU vs the reference's own backward() (fp64 golden)."""
+@pytest.mark.parametrize("impl", ["direct", "autograd"])
+def test_class_backward_matches_reference(name, cls, kind, impl):
+    """The drop-in class on the GPU vs the reference's own backward() (fp64 golden), both forms of the closure."""
     from test_host_logic import feed
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     model = cls(g["layers"].tolist(), g["lb"], g["ub"])
+    model.closure_impl = impl
     _load_theta(model, g["theta"])
     feed(model, g, kind)
     model.iter = 1

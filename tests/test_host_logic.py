@@ -82,12 +82,14 @@ def feed(model, g, kind):
         model.set_training_data(d["x0"], d["u0"], d["v0"], d["tb"], Xf, earliest_solutions=es)
 
 
+@pytest.mark.parametrize("impl", ["direct", "autograd"])
 @pytest.mark.parametrize("name,cls,kind", CASES)
-def test_backward_matches_reference_backward(name, cls, kind):
+def test_backward_matches_reference_backward(name, cls, kind, impl):
     """loss and flat gradient of the full backward() vs the reference's own
-    backward() (fp64 golden), fp32 tolerance."""
+    backward() (fp64 golden), fp32 tolerance; both forms of the closure (PhysicsInformedNN.closure_impl)."""
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     model = make_model(g, cls)
+    model.closure_impl = impl
     feed(model, g, kind)
     model.iter = 1
     loss = model.backward()
