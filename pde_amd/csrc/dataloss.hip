@@ -25,18 +25,20 @@ __device__ __forceinline__ double wave_sum_d(double v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_data_loss(const float *__restrict__ out, const float *__restrict__ tgt0, int n0, int nb,
+constexpr int LOSS_THREADS = 1024;      // one workgroup (fixed summation order); the bc classes' loss1 batch is ~10^5 rows
+
+__global__ __launch_bounds__(LOSS_THREADS) void k_data_loss(const float *__restrict__ out, const float *__restrict__ tgt0, int n0, int nb,
                                                     int nout, int dirichlet, float *__restrict__ losses)
 {
-    __shared__ double part[2][4];
+    __shared__ double part[2][LOSS_THREADS / 64];
     double s0 = 0.0, sb = 0.0;
     const int e0 = n0 * nout;
-    for (int i = threadIdx.x; i < e0; i += 256) {
+    for (int i = threadIdx.x; i < e0; i += LOSS_THREADS) {
         const float r = out[i] - tgt0[i];
         s0 += (double)r * r;
     }
     const int eb = (dirichlet ? 2 * nb : nb) * nout;
-    for (int i = threadIdx.x; i < eb; i += 256) {
+    for (int i = threadIdx.x; i < eb; i += LOSS_THREADS) {
         const float r = dirichlet ? out[e0 + i] : out[e0 + i] - out[e0 + nb * nout + i];
         sb += (double)r * r;
     }
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(256) void k_data_loss(const float *__restrict__ out
     if ((threadIdx.x & 63) == 0) { part[0][wv] = s0; part[1][wv] = sb; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double a = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
-        const double b = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < LOSS_THREADS / 64; ++w) { a += part[0][w]; b += part[1][w]; }
         losses[0] = n0 > 0 ? (float)(a / n0) : 0.0f;
         losses[1] = nb > 0 ? (float)(b / nb) : 0.0f;
     }
@@ -84,7 +86,7 @@ int pinn_data_loss(const float *out, const float *tgt0, int32_t n0, int32_t nb, 
 {
     if (!out || !losses || (n0 > 0 && !tgt0)) return PINN_ERR_NULL;
     if (n0 < 0 || nb < 0 || nout < 1 || nout > PINN_MAX_OUT) return PINN_ERR_INVALID_DESC;
-    hipLaunchKernelGGL(k_data_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, out, tgt0, n0, nb, nout, dirichlet, losses);
+    hipLaunchKernelGGL(k_data_loss, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, out, tgt0, n0, nb, nout, dirichlet, losses);
     return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 
