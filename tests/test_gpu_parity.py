@@ -458,6 +458,29 @@ def test_class_backward_matches_reference(name, cls, kind, impl):
     assert rel(grad, g["grad_full64"]) <= max(1e-5, 5 * ref_gerr)
 
 
+@pytest.mark.parametrize("impl", ["direct", "autograd"])
+def test_eager_closure_on_two_streams_matches_one_stream(impl):
+    """backward() with the collocation kernel on the second stream (overlap_streams = True: what wide nets get
+    automatically and what the captured steps use) gives the loss and gradient of the one-stream closure."""
+    from test_host_logic import feed
+    g = np.load(os.path.join(GOLDEN, "gnss_w100_ckpt.npz"))
+    res = {}
+    for ov in (False, True):
+        model = scripts.gnss.sw.PhysicsInformedNN(g["layers"].tolist(), g["lb"], g["ub"])
+        model.closure_impl, model.overlap_streams = impl, ov
+        _load_theta(model, g["theta"])
+        feed(model, g, "gnss_sw")
+        model.iter = 1
+        for _ in range(3):                                  # repeated calls: buffers of one call must not leak into the next
+            for p in model.dnn.parameters():
+                p.grad = None
+            loss = model.backward()
+        torch.cuda.synchronize()
+        res[ov] = (loss.item(), torch.cat([p.grad.reshape(-1) for p in model.dnn.parameters()]).cpu().numpy().astype(np.float64))
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0])
+    assert rel(res[True][1], res[False][1]) < 2e-6
+
+
 def test_predict_known_answer_error_txt(golden_dir):
     """error.txt:101-102 — PI 73.pth on the 201x512 grid -> 3.743270e-01, on the GPU."""
     g = np.load(os.path.join(golden_dir, "predict_kdv7_73.npz"))
