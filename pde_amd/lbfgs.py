@@ -103,6 +103,7 @@ class LBFGS(torch.optim.Optimizer):
         st.setdefault("func_evals", 0)
         st.setdefault("n_iter", 0)
         self.host_syncs = 0
+        self._x_at = None
 
     # ---- flat gradient -------------------------------------------------------------------
     def _intact(self):
@@ -172,6 +173,7 @@ class LBFGS(torch.optim.Optimizer):
     def _evaluate_async(self, closure, x0, t):
         """enqueue the evaluation; returns (flat gradient copy, device [f, g.d, max|g|, sum|g|]) without reading"""
         torch.add(x0, self._d, alpha=t, out=self._x)
+        self._x_at = t                      # the parameters now hold x0 + t d
         loss = closure()
         g = self._gather()
         return g.clone(), self._k.eval_stats(g, self._d, loss)
@@ -290,7 +292,9 @@ class LBFGS(torch.optim.Optimizer):
                     x0 = self._x.clone()
                 pt, ls_evals = self._strong_wolfe(closure, x0, t, f, g, gtd, gmax, dmax, first_point=spec)
                 t, f, g, gmax = pt.t, pt.f, pt.g, pt.gmax
-                torch.add(x0, self._d, alpha=t, out=self._x)
+                if self._x_at != t:         # (the accepted point is usually the last one evaluated: already there)
+                    torch.add(x0, self._d, alpha=t, out=self._x)
+                    self._x_at = t
             else:
                 self._x.add_(self._d, alpha=t)
                 ls_evals = 0
