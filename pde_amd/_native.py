@@ -104,15 +104,20 @@ def _cur_stream(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def data_loss(out, tgt0, n0, nb, dirichlet):
+def data_loss(out, tgt0, n0, nb, dirichlet, losses=None):
     """[loss0, loss_b] of the reference's backward() from out = net_u([IC | lower | upper rows]) in one launch
-    (include/pinnjet.h, pinn_data_loss).  nb = 0: a plain mean-square term (loss1, loss_prev)."""
+    (include/pinnjet.h, pinn_data_loss).  nb = 0: a plain mean-square term (loss1, loss_prev).
+    `losses`: where to write the two floats (default: a new tensor)."""
     assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == n0 + 2 * nb
     tgt0 = tgt0.contiguous()
     assert tgt0.shape == (n0, out.shape[1]) and tgt0.dtype == torch.float32
-    losses = torch.empty(2, dtype=torch.float32, device=out.device)
-    _check(load_library().pinn_data_loss(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
-                                         losses.data_ptr(), _cur_stream(out)), "pinn_data_loss")
+    assert tgt0.device == out.device
+    if losses is None:
+        losses = torch.empty(2, dtype=torch.float32, device=out.device)
+    assert losses.dtype == torch.float32 and losses.numel() == 2 and losses.is_contiguous() and losses.device == out.device
+    with torch.cuda.device(out.device):
+        _check(load_library().pinn_data_loss(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
+                                             losses.data_ptr(), _cur_stream(out)), "pinn_data_loss")
     return losses
 
 
@@ -121,10 +126,12 @@ def data_loss_cotangent(out, tgt0, n0, nb, dirichlet, g0, gb):
     tgt0 = tgt0.contiguous()
     g0 = g0.reshape(1).float().contiguous()
     gb = gb.reshape(1).float().contiguous()
+    assert tgt0.device == out.device and g0.device == out.device and gb.device == out.device
     gbar = torch.empty_like(out)
-    _check(load_library().pinn_data_loss_cotangent(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
-                                                   g0.data_ptr(), gb.data_ptr(), gbar.data_ptr(), _cur_stream(out)),
-           "pinn_data_loss_cotangent")
+    with torch.cuda.device(out.device):
+        _check(load_library().pinn_data_loss_cotangent(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
+                                                       g0.data_ptr(), gb.data_ptr(), gbar.data_ptr(), _cur_stream(out)),
+               "pinn_data_loss_cotangent")
     return gbar
 
 

@@ -41,14 +41,17 @@ constexpr int MAXF = 3;     // residual components per point: two outputs + one 
 // (relative error < 0.3 ulp, r is exact for n = 0);  e = exp(a) = s (1 + p), s = 2^n.  Then
 //     1 - e = (1 - s) - s p     (exact for n = 0: no cancellation error at all),
 //     1 + e = (1 + s) + s p,    tanh = (1 - e)/(1 + e),    sech^2 = 4 e / (1 + e)^2,
-// with one Newton step on the reciprocal and one on the quotient.  28 VALU instructions (one
-// transcendental), 7 more than the version it replaces.  Accuracy on the GPU: tools/ubench/tanh_accuracy.hip.
+// with one Newton step on the reciprocal and one on the quotient.  ~31 VALU instructions (one
+// transcendental).  Accuracy on the GPU: tools/ubench/tanh_accuracy.hip.
 __device__ __forceinline__ float tanh_sech2(float x, float &w0)
 {
-    const float ax = fabsf(x);
+    // |x| > 22: tanh = 1 and sech^2 < 4 e^-44 = 3e-19 in float.  The ARGUMENT is clamped (a select, so that NaN
+    // stays NaN), not just the exponent: with only n clamped the remainder r = a - n ln2 of a large |x| is not
+    // small, the expm1 polynomial blows up and tanh(500) came out as 0.04 (round-2 regression).
+    const float ax0 = fabsf(x);
+    const float ax = ax0 > 22.0f ? 22.0f : ax0;
     const float a = -2.0f * ax;
-    float nf = __builtin_rintf(a * 1.44269504f);
-    nf = fmaxf(nf, -64.0f);                       // |x| > 22: e = 2^-64 (1 + p), tanh = 1 and sech^2 ~ 0 in float
+    const float nf = __builtin_rintf(a * 1.44269504f);   // >= -64
     float r = fmaf(nf, -0.693145752f, a);         // ln2 = hi + lo, hi with 9 trailing zero bits: n * hi is exact
     r = fmaf(nf, -1.42860677e-6f, r);
     float q = 1.0f / 40320.0f;
@@ -67,7 +70,9 @@ __device__ __forceinline__ float tanh_sech2(float x, float &w0)
     rc = fmaf(fmaf(-den, rc, 1.0f), rc, rc);
     float y = num * rc;
     y = fmaf(fmaf(-den, y, num), rc, y);
-    w0 = (e4 * rc) * rc;
+    // (exactly 0 beyond the clamp, like 1 - tanhf(x)^2: a constant 3e-19 there would be multiplied by powers of
+    // the pre-activation's slope in the jet recurrences)
+    w0 = ax0 > 22.0f ? 0.0f : (e4 * rc) * rc;
     return copysignf(y, x);
 }
 

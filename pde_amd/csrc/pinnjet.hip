@@ -371,10 +371,12 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
     if (kernel == PINN_KERNEL_VALU && (size_t)(kd.P + MAXF) * sizeof(float) > 160 * 1024) { delete h; return PINN_ERR_UNSUPPORTED; }
     h->kernel = kernel;
     h->mfma_grid = h->n_cu;      // persistent kernels: at most one workgroup per CU
-    if (const char *e = getenv("PINN_SPARE_CUS")) {          // development knob
+#ifdef PINN_DEV_KNOBS                                        // development builds only (tools/dev_build.sh -DPINN_DEV_KNOBS)
+    if (const char *e = getenv("PINN_SPARE_CUS")) {
         const int v = atoi(e);
         if (v >= 0 && v <= h->n_cu / 4) h->spare_cus = v;
     }
+#endif
     // set-up work of the no-allocation entry point: this device's address of the static scratch array
     { const int rc = static_scratch_lookup(h->device); if (rc) { delete h; return rc; } }
     *out = h;

@@ -60,6 +60,7 @@ class LBFGS(torch.optim.Optimizer):
     (NetU.flat_theta()); when omitted the parameters are re-pointed into a new flat buffer."""
 
     speculate = True      # step(): first line-search evaluation enqueued before the direction's statistics are read
+    on_discard = None     # callable: a speculative closure evaluation was made in vain and has been undone
 
     def __init__(self, params, lr=1, max_iter=20, max_eval=None, tolerance_grad=1e-7, tolerance_change=1e-9,
                  history_size=100, line_search_fn=None, flat_params=None, kernels=None):
@@ -274,7 +275,9 @@ class LBFGS(torch.optim.Optimizer):
                 # statistics say: that evaluation is enqueued before they are read, and both come back in ONE
                 # blocking read instead of two.  Decisions and evaluation counts are those of the plain order;
                 # only when the search direction turns out not to descend (the break below, i.e. the last
-                # iteration of a run) has one evaluation been made in vain - it is undone and not counted.
+                # iteration of a run) has one evaluation been made in vain.  It is undone: weights and flat
+                # gradient are put back, it is not counted in func_evals, and `on_discard` (if set) lets the
+                # closure's owner roll back its own side effects (PhysicsInformedNN: the iteration counter).
                 x0 = self._x.clone()
                 gs, ev = self._evaluate_async(closure, x0, lr)
                 (gtd, gsum, dmax, _gm, _cnt, _hd, _, _), (fs, gtds, gmaxs, _) = self._read2(dstats, ev)
@@ -286,6 +289,9 @@ class LBFGS(torch.optim.Optimizer):
             if gtd > -tol_x:
                 if spec is not None:
                     self._x.copy_(x0)
+                    self._g.copy_(g)
+                    if self.on_discard is not None:
+                        self.on_discard()
                 break
             if wolfe:
                 if x0 is None:

@@ -58,18 +58,24 @@ def xavier(m):
             torch.nn.init.zeros_(m.bias)
 
 
-def data_loss_values(out, tgt0, n0, nb, dirichlet):
+def data_loss_values(out, tgt0, n0, nb, dirichlet, out_losses=None):
     """[loss0, loss_b] from out = net_u([IC | lower | upper rows]) (reference :99-105; Burgers :109).  GPU: one
-    launch (pinn_data_loss); CPU tensors (the tests of the host logic): the torch expressions."""
+    launch (pinn_data_loss); CPU tensors (the tests of the host logic): the torch expressions.
+    `out_losses`: two consecutive floats to write them to (a slot of a sharded closure's packed buffer)."""
     if out.is_cuda:
         from ._native import data_loss
-        return data_loss(out, tgt0, n0, nb, dirichlet)
+        return data_loss(out, tgt0, n0, nb, dirichlet, out_losses)
     r0 = out[:n0] - tgt0
     l0 = (r0 * r0).sum() / n0
     if nb == 0:
-        return torch.stack([l0, torch.zeros_like(l0)])
-    rb = out[n0:] if dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
-    return torch.stack([l0, (rb * rb).sum() / nb])
+        res = torch.stack([l0, torch.zeros_like(l0)])
+    else:
+        rb = out[n0:] if dirichlet else out[n0:n0 + nb] - out[n0 + nb:]
+        res = torch.stack([l0, (rb * rb).sum() / nb])
+    if out_losses is not None:
+        out_losses.copy_(res)
+        return out_losses
+    return res
 
 
 def data_loss_cot(out, tgt0, n0, nb, dirichlet, g0, gb):

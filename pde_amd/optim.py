@@ -36,11 +36,33 @@ class FusedAdam(torch.optim.Optimizer):
         dev = flat_params.device
         n = flat_params.numel()
         self._g = torch.zeros(n, dtype=torch.float32, device=dev)
-        st = self.state[self._params[0]]
-        st["exp_avg"] = torch.zeros(n, dtype=torch.float32, device=dev)
-        st["exp_avg_sq"] = torch.zeros(n, dtype=torch.float32, device=dev)
-        st["device_state"] = torch.zeros(4, dtype=torch.float64, device=dev)   # step, beta1^t, beta2^t, ticket
+        # The moments (flat, unlike the parameters they belong to) and the float64 device-side counters live
+        # OUTSIDE `self.state`: torch.optim.Optimizer.load_state_dict casts every floating state tensor to its
+        # parameter's dtype, which would hand the kernel a float32 buffer where it reads doubles.
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.device_state = torch.zeros(4, dtype=torch.float64, device=dev)   # step, beta1^t, beta2^t, ticket
         self._attach_grads()
+
+    def state_dict(self):
+        """torch's layout plus `fused`: the flat moments and the float64 counters, dtypes preserved."""
+        sd = super().state_dict()
+        sd["fused"] = {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                       "device_state": self.device_state.clone()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        sd = dict(state_dict)
+        fused = sd.pop("fused", None)
+        super().load_state_dict(sd)
+        self._params = self.param_groups[0]["params"]
+        if fused is not None:
+            for name in ("exp_avg", "exp_avg_sq", "device_state"):
+                dst, src = getattr(self, name), fused[name]
+                if src.shape != dst.shape or src.dtype != dst.dtype:
+                    raise ValueError("FusedAdam.load_state_dict: %s is %s %s, expected %s %s"
+                                     % (name, tuple(src.shape), src.dtype, tuple(dst.shape), dst.dtype))
+                dst.copy_(src)
 
     def _intact(self):
         """every `.grad` is still the view this optimizer attached (identity checks: the per-step host path)"""
@@ -81,7 +103,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     @property
     def step_count(self):
-        return int(self.state[self._params[0]]["device_state"][0].item())
+        return int(self.device_state[0].item())
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -91,11 +113,10 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         self._gather()
         grp = self.param_groups[0]
-        st = self.state[self._params[0]]
         dev = self._x.device
         with torch.cuda.device(dev):
-            _check(self.lib.pinn_adam_step(self._x.data_ptr(), self._g.data_ptr(), st["exp_avg"].data_ptr(),
-                                           st["exp_avg_sq"].data_ptr(), st["device_state"].data_ptr(), self._x.numel(),
+            _check(self.lib.pinn_adam_step(self._x.data_ptr(), self._g.data_ptr(), self.exp_avg.data_ptr(),
+                                           self.exp_avg_sq.data_ptr(), self.device_state.data_ptr(), self._x.numel(),
                                            float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
                                            float(grp["eps"]), float(grp["weight_decay"]), 1 if grp["decoupled"] else 0,
                                            ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),

@@ -421,16 +421,93 @@ class PhysicsInformedNN:
             loss_prev = _MseLossFn.apply(self.dnn, self.X_prev, self._tgt_prev, self.dnn.grad_leaf())
         return loss1, loss_prev, loss_s
 
-    def _loss_terms_sharded(self):
+    # layout of the tail of a sharded closure's packed buffer (floats after the P gradient entries)
+    _T_SUMS, _T_L0, _T_L1, _T_LPREV, _T_LS, _T_SIZE = 0, 3, 5, 7, 9, 10
+
+    def _loss_terms_sharded(self, data_terms=True):
         """The closure of a sharded run: every rank evaluates the collocation term on ITS
-        shard (value and gradient already scaled by 1/N_global), rank 0 alone evaluates the data terms
+        shard (gradient already scaled by 1/N_global), rank 0 alone evaluates the data terms
         (IC, boundary, loss1, loss_prev, loss_s: at most a few thousand points), and ONE all-reduce(SUM) of
-        [flat gradient (P), loss0, loss_b, loss_f, loss1, loss_prev, loss_s, reg] gives every rank the same bits for
-        everything an optimizer reads: the float32 sums inside the kernels depend on wave arrival order
-        (LDS / memory-side float adds), so nothing a rank computed by itself may reach `.grad` or the
+        [flat gradient (P) | sum_p f_c^2 (3) | loss0, loss_b | loss1 | loss_prev | loss_s] gives every rank the
+        same bits for everything an optimizer reads: the float32 sums inside the kernels depend on wave arrival
+        order (LDS / memory-side float adds), so nothing a rank computed by itself may reach `.grad` or the
         returned loss.  Adam/AdamW (elementwise) and pde_amd.lbfgs.LBFGS (fixed-order reductions) then
         make identical updates and identical line-search decisions: the replicas stay bit-identical
-        without a broadcast, and the closure counts agree (no mismatched collectives)."""
+        without a broadcast, and the closure counts agree (no mismatched collectives).
+
+        `closure_impl = "direct"` (default): no autograd graph — the kernels' accumulate outputs ARE the packed
+        buffer (the collocation kernel adds its gradient and its sums into it, the data-loss launches write
+        their slots, every net_u vjp adds into the same P entries), so the closure is the launches, one
+        all-reduce on the buffer and a handful of scalar ops; nothing in it synchronises or allocates after
+        the first call, which makes it capturable where the backend's all-reduce is (RCCL).
+        `data_terms=False`: the collocation term and the collective alone (what bench.py times on N > 1 GPUs)."""
+        if self.closure_impl != "direct":
+            return self._loss_terms_sharded_autograd()
+        import torch.distributed as dist
+        from .nn import all_reduce_sum
+        v = self.variant
+        dnn, eng = self.dnn, self.dnn.engine
+        theta = dnn.flat_theta()
+        P, nf, N = theta.numel(), self.engine_f.nf, float(self.n_f_global)
+        T = self
+        with torch.no_grad():
+            buf = torch.zeros(P + T._T_SIZE, dtype=torch.float32, device=theta.device)
+            g, tail = buf[:P], buf[P:]
+            if self.xf.shape[0] > 0:
+                self.engine_f.loss_grad(theta, self.xf, self.tf, 1.0 / N, tail[T._T_SUMS:T._T_SUMS + nf], g)
+            has1 = v.style == "bc" and self.u1 is not None
+            hasp = v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0
+            hass = bool(getattr(self, "earliest_solutions", ()))
+            if data_terms and dist.get_rank(self.group) == 0:
+                one = getattr(self, "_one", None)
+                if one is None or one.device != theta.device:
+                    one = self._one = torch.ones((), dtype=torch.float32, device=theta.device)
+                n0, nb = self.x0.shape[0], self.x_lb.shape[0]
+                dirichlet = v.bc == "dirichlet"
+                out = eng.forward(theta, self._X_data, None)
+                data_loss_values(out, self._tgt0, n0, nb, dirichlet, out_losses=tail[T._T_L0:T._T_L0 + 2])
+                eng.forward_vjp(theta, self._X_data, None, data_loss_cot(out, self._tgt0, n0, nb, dirichlet, one, one), g)
+
+                def mse_term(X, tgt, slot):
+                    o = eng.forward(theta, X, None)
+                    data_loss_values(o, tgt, o.shape[0], 0, False, out_losses=tail[slot:slot + 2])
+                    eng.forward_vjp(theta, X, None, data_loss_cot(o, tgt, o.shape[0], 0, False, one, one), g)
+
+                if has1:
+                    mse_term(self._X1, self._tgt1, T._T_L1)
+                if hasp:
+                    mse_term(self.X_prev, self._tgt_prev, T._T_LPREV)
+                if hass:      # the list-of-terms loss_s (broadcasting targets) stays on autograd, through one leaf
+                    leaf = dnn.collect_leaf()
+                    try:
+                        with torch.enable_grad():
+                            ls = 0
+                            for X_ref, h_ref in self.earliest_solutions:
+                                ls = ls + torch.mean(torch.square(dnn(X_ref) - h_ref))
+                            gs, = torch.autograd.grad(ls, leaf)
+                    finally:
+                        dnn.end_collect()
+                    g.add_(gs)
+                    tail[T._T_LS] = ls.detach()
+            all_reduce_sum(buf, self.group)
+            dnn.distribute_flat_grad(g)
+            sums = tail[T._T_SUMS:T._T_SUMS + nf]
+            self.engine_f.last_sums = sums
+            loss_f = (sums[0] if nf == 1 else sums.sum()) / N
+            loss = tail[T._T_L0] + tail[T._T_L0 + 1] + loss_f
+            if has1:
+                loss = loss + tail[T._T_L1]
+            if hasp:
+                loss = loss + tail[T._T_LPREV]
+            if hass:
+                loss = loss + tail[T._T_LS]
+        return {"loss": loss, "loss0": tail[T._T_L0], "loss_b": tail[T._T_L0 + 1], "loss_f": loss_f,
+                "loss1": tail[T._T_L1] if has1 else None, "loss_prev": tail[T._T_LPREV] if hasp else 0,
+                "loss_s": tail[T._T_LS] if hass else 0, "loss_reg": self._reg_share()}
+
+    def _loss_terms_sharded_autograd(self):
+        """`closure_impl = "autograd"` form of the sharded closure: the same terms as autograd ops through one
+        hook-free leaf, `torch.autograd.grad` for the rank-local flat gradient, then the one all-reduce."""
         import torch.distributed as dist
         from .nn import all_reduce_sum
         v = self.variant
@@ -590,12 +667,16 @@ class PhysicsInformedNN:
         def LBFGS_callback():
             self.optimizer_LBFGS.zero_grad()
             return self.backward()
-        if LBFGS_max_iter > 0:
-            closure = LBFGS_callback
-            if self.use_hip_graph and self.group is None and torch.device(self.device).type == "cuda" \
-                    and hasattr(self.optimizer_LBFGS, "flat_grad"):
-                closure = self._graph_closure() or LBFGS_callback
-            self.optimizer_LBFGS.step(closure)
+        # (the reference always makes this call, :161 - with LBFGS_max_iter = 0 torch evaluates the closure once)
+        closure = LBFGS_callback
+        if LBFGS_max_iter > 0 and self.use_hip_graph and self.group is None and torch.device(self.device).type == "cuda" \
+                and hasattr(self.optimizer_LBFGS, "flat_grad"):
+            closure = self._graph_closure() or LBFGS_callback
+        if hasattr(self.optimizer_LBFGS, "on_discard"):
+            def _undo_iteration():      # a speculative evaluation pde_amd.lbfgs.LBFGS made in vain: not an iteration
+                self.iter -= 1
+            self.optimizer_LBFGS.on_discard = _undo_iteration
+        self.optimizer_LBFGS.step(closure)
         elapsed = time.time() - start_time
         if self.logfilename is not None:
             self.writer.write('Training time: %.4f' % (elapsed))

@@ -46,6 +46,17 @@ def _worker(rank, world, port, name, out):
     m.iter = 1
     loss = m.backward()
     out[rank] = (n_local, float(loss), flat_grad(m).copy())
+    # the autograd form of the sharded closure (closure_impl = "autograd") hands out the same numbers
+    for p in m.dnn.parameters():
+        p.grad = None
+    m.closure_impl = "autograd"
+    loss_a = m.backward()
+    ga = flat_grad(m).copy()
+    m.closure_impl = "direct"
+    assert abs(float(loss_a) - out[rank][1]) <= 2e-6 * abs(out[rank][1])
+    assert np.linalg.norm(ga - out[rank][2]) <= 2e-6 * np.linalg.norm(out[rank][2])
+    for p in m.dnn.parameters():
+        p.grad = None
     # two Adam steps keep the replicas identical without any broadcast
     m.train(2, LBFGS_max_iter=0)
     th = m.dnn.flat_theta().clone()

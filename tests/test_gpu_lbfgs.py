@@ -236,6 +236,19 @@ def test_fused_adam_follows_torch_adam(adamw):
     assert float((fa_buf.detach().double() - ref).norm() / ref.norm()) < 1e-6
     m_ref = torch.cat([ta.state[p]["exp_avg"].reshape(-1) for p in pt]).double()
     v_ref = torch.cat([ta.state[p]["exp_avg_sq"].reshape(-1) for p in pt]).double()
-    st = fa.state[pf[0]]
-    assert float((st["exp_avg"].double() - m_ref).norm() / m_ref.norm()) < 1e-6
-    assert float((st["exp_avg_sq"].double() - v_ref).norm() / v_ref.norm()) < 1e-6
+    assert float((fa.exp_avg.double() - m_ref).norm() / m_ref.norm()) < 1e-6
+    assert float((fa.exp_avg_sq.double() - v_ref).norm() / v_ref.norm()) < 1e-6
+    # state_dict round trip into a fresh optimizer (dtypes preserved: the counters are float64 on the device),
+    # then both take the same further steps
+    fb_buf = fa_buf.detach().clone()
+    fb = FusedAdam(views(fb_buf), flat_params=fb_buf, decoupled=adamw, **kw)
+    fb.load_state_dict(fa.state_dict())
+    assert fb.step_count == 60 and fb.device_state.dtype == torch.float64
+    for it in range(3):
+        g = torch.cos(torch.arange(n, device=dev) * 0.02 + it)
+        for o in (fa, fb):
+            o.zero_grad()
+            o.flat_grad().add_(g)
+            o.step()
+    torch.cuda.synchronize()
+    assert fb.step_count == 63 and torch.equal(fb_buf, fa_buf.detach())

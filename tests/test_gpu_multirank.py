@@ -58,8 +58,8 @@ def test_two_ranks_real_kernels_stay_bit_identical(case, tmp_path):
     a, b = res
     assert a["n_local"] + b["n_local"] in (3001, 2003) and abs(a["n_local"] - b["n_local"]) <= 1
     assert a["lbfgs_module"] == b["lbfgs_module"] == "pde_amd.lbfgs"
-    assert a["iter_adam"] == b["iter_adam"] == 130
-    assert a["iter"] == b["iter"] > 130                       # same number of closure evaluations
+    assert a["iter_adam"] == b["iter_adam"] == 131               # 130 Adam iterations + the closure of LBFGS.step(max_iter=0)
+    assert a["iter"] == b["iter"] > 131                       # same number of closure evaluations
     assert a["func_evals"] == b["func_evals"] > 1
     assert a["finite"] and b["finite"]
     assert a["theta_adam_hex"] == b["theta_adam_hex"] and a["theta_adam_sum"] == b["theta_adam_sum"]

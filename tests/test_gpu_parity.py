@@ -391,6 +391,50 @@ def test_run_to_run_agreement(name, kname, kernel):
         assert rel(r[eng.P:], runs[0][eng.P:]) < 1e-6
 
 
+@pytest.mark.parametrize("kname,kernel", KINDS)
+@pytest.mark.parametrize("scale", [40.0, 3e3, 1e6, 1e30])
+def test_saturated_preactivations(scale, kname, kernel):
+    """tanh far outside [-20, 20] (diverging weights, large strong-Wolfe trial steps): tanh_sech2 clamps its
+    ARGUMENT, so |z| = 1e2 .. 1e30 and +-inf give tanh = +-1 and sech^2 = 0 like torch's tanh / 1 - tanh^2 do,
+    not the blown-up polynomial of the round-2 routine (tanh(500) = 0.04).  Plain forward + vjp at every scale;
+    the 5th-order jets at the moderately saturated one (larger slopes overflow float32 in ANY implementation)."""
+    layers = [2, 50, 50, 1]
+    lb, ub = np.array([-4.0, -1.0]), np.array([4.0, 1.0])
+    rng = np.random.default_rng(3)
+    theta = []
+    for i in range(len(layers) - 1):
+        fi, fo = layers[i], layers[i + 1]
+        theta.append(rng.standard_normal(fi * fo) * np.sqrt(2.0 / (fi + fo)) * (scale if i == 0 else 1.0))
+        theta.append(0.1 * rng.standard_normal(fo))
+    theta = np.concatenate(theta).astype(np.float32)
+    n = 777
+    X = (lb + (ub - lb) * rng.random((n, 2))).astype(np.float32)
+    eng = NativeEngine(equations.get("none"), layers, lb.astype(np.float32), ub.astype(np.float32), dev(), kernel=kernel)
+    o = Oracle("none", layers, lb, ub)
+    out = eng.forward(cu(theta), cu(X), None).cpu().numpy()
+    der, _ = o.forward(theta.astype(np.float64), X[:, 0], X[:, 1])
+    assert np.isfinite(out).all()
+    assert rel(out, der[:, :, 0]) < 1e-5
+    gb = rng.standard_normal((n, 1)).astype(np.float32)
+    grad = torch.zeros(eng.P, device=dev())
+    eng.forward_vjp(cu(theta), cu(X), None, cu(gb), grad)
+    _, gref = o.loss_grad(theta.astype(np.float64), X[:, 0], X[:, 1], gbar=gb.astype(np.float64))
+    torch.cuda.synchronize()
+    assert np.isfinite(grad.cpu().numpy()).all()
+    assert rel(grad.cpu().numpy(), gref) < (1e-5 if scale < 1e29 else 1e-4)
+    if scale <= 40.0:
+        e5 = NativeEngine(equations.get("kdv5"), layers, lb.astype(np.float32), ub.astype(np.float32), dev(), kernel=kernel)
+        o5 = Oracle("kdv5", layers, lb, ub)
+        f, d = e5.residual_fwd(cu(theta), cu(X[:, 0]), cu(X[:, 1]), want_derivs=True)
+        d64, _ = o5.forward(theta.astype(np.float64), X[:, 0], X[:, 1])
+        z0 = np.abs(theta[:100].reshape(50, 2).astype(np.float64) @ (2 * (X.astype(np.float64) - lb) / (ub - lb) - 1).T)
+        assert z0.max() > 25.0 and (z0 < 9.0).mean() > 0.1      # both saturated (beyond the clamp) and active neurons present
+        d = d.cpu().numpy()
+        assert np.isfinite(d).all()
+        for j in range(d.shape[2]):
+            assert rel(d[:, :, j], d64[:, :, j]) < 2e-5, j
+
+
 NOISE_CASES = sorted(fn[6:-4] for fn in os.listdir(GOLDEN) if fn.startswith("noise_"))
 
 

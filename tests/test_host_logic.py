@@ -164,7 +164,9 @@ def test_adam_step_runs_and_decreases_loss():
     m = make_model(g, scripts.burgers.PI.PhysicsInformedNN)
     feed(m, g, "burgers")
     m.train(3, LBFGS_max_iter=0)
-    assert m.iter == 3
+    # three Adam iterations + the one closure evaluation of LBFGS.step, which the reference's train() always
+    # calls (7kdv/PI-7kdv3soliton.py:161; with max_iter = 0 torch evaluates the closure once and returns)
+    assert m.iter == 4
 
 
 def test_script_literals_match_reference():
