@@ -8,8 +8,9 @@ closure-equivalent of the PDE term: forward jets + residual + sum f^2 + gradient
 the weights over the rank's shard of collocation points, plus (N>1) the
 all-reduce of [grad, sum f^2] that keeps L-BFGS consistent across ranks.
 Workload = BASELINE.json configs[2]: 7th-order KdV 3-soliton, net [2,50x4,1],
-1M synthetic collocation points PER GPU (weak scaling), weights
-xavier-normal(seed 1234), points uniform in [-15,15]x[-0.5,0.5].
+1M synthetic collocation points PER GPU (weak scaling), weights of the reference's
+shipped checkpoint 7kdv/model/PI 73.pth (`--weights xavier`:
+xavier-normal, seed 1234), points uniform in [-15,15]x[-0.5,0.5].
 
 Besides the contract fields the JSON line carries
   roofline      FP32 compute roofline of the dominant kernel (HIP-event timed)
@@ -34,12 +35,15 @@ sys.path.insert(0, ROOT)
 FLOPS_PER_POINT = {"kdv7_3sol": 4.94e5, "kdv5": 3.68e5, "burgers": 1.96e5, "gnss": 9.5e5, "ch": 5.8e5}
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector == FP32-input MFMA
 
+# `ckpt`: golden fixture holding the weights of the reference's shipped checkpoint for this config (SURVEY 8(d):
+# C3 = 7kdv/model/PI 73.pth, C2 = 5kdv/model/PINN1t-2.pth, C4 = NLS/model/adamWsw(0.1+0)t-2_1.pth); configs without a
+# checkpoint of their shape (Burgers 8x20, CH width 64) use xavier-normal weights, seed 1234.
 WORKLOADS = {
-    "kdv7": dict(eq="kdv7_3sol", layers=[2, 50, 50, 50, 50, 1], lb=[-15.0, -0.5], ub=[15.0, 0.5],
+    "kdv7": dict(eq="kdv7_3sol", layers=[2, 50, 50, 50, 50, 1], lb=[-15.0, -0.5], ub=[15.0, 0.5], ckpt="kdv7_3sol_ckpt",
                  n=1_000_000, family="kdv7_3soliton", name="7kdv PI-7kdv3soliton, [2,50x4,1], N_f=1M per GPU"),
-    "kdv5": dict(eq="kdv5", layers=[2, 50, 50, 50, 50, 1], lb=[-10.0, -2.0], ub=[10.0, 2.0],
+    "kdv5": dict(eq="kdv5", layers=[2, 50, 50, 50, 50, 1], lb=[-10.0, -2.0], ub=[10.0, 2.0], ckpt="kdv5_ckpt",
                  n=100_000, family="kdv5_1soliton", name="5kdv PI-51, [2,50x4,1], N_f=100k"),
-    "gnss": dict(eq="gnss", layers=[2, 100, 100, 100, 100, 2], lb=[-5.0, -2.0], ub=[5.0, 0.0],
+    "gnss": dict(eq="gnss", layers=[2, 100, 100, 100, 100, 2], lb=[-5.0, -2.0], ub=[5.0, 0.0], ckpt="gnss_w100_ckpt",
                  n=2_000_000, family="gnss", name="NLS sw-GNSS-adamW, [2,100x4,2], N_f=2M"),
     "ch": dict(eq="ch", layers=[2, 64, 64, 64, 64, 1], lb=[-15.0, -1.0], ub=[15.0, 1.0],
                n=1_250_000, family="camassa_holm", name="CH PI, [2,64x4,1], N_f=1.25M per GPU (10M over 8)"),
@@ -48,28 +52,44 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(w, budget_s=25.0):
-    """Reference method on the host: nested autograd (oracle/torch_ref.py), fp32."""
+def checkpoint_theta(w):
+    """flat weights of the reference's shipped checkpoint for this workload (tests/golden fixture), or None"""
+    name = w.get("ckpt")
+    if not name:
+        return None
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    return g["theta"].astype(np.float32) if g["layers"].tolist() == w["layers"] else None
+
+
+def cpu_baseline(w, theta=None, budget_s=25.0):
+    """Reference method on the host: nested autograd (oracle/torch_ref.py), fp32: median of 8 closures after
+    2 warm-ups (fewer only if the time budget runs out), fastest and slowest reported."""
     from oracle import torch_ref
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1))
     torch.set_num_threads(cores)
     net = torch_ref.make_dnn(w["layers"], w["lb"], w["ub"], seed=1234)
+    if theta is not None:
+        torch_ref.load_flat_theta(net, theta)
     rng = np.random.default_rng(1234)
     lb, ub = np.array(w["lb"]), np.array(w["ub"])
     n = 20_000
     X = torch.tensor((lb + (ub - lb) * rng.random((n, 2))).astype(np.float32))
     x, t = X[:, 0:1].contiguous(), X[:, 1:2].contiguous()
-    torch_ref.loss_f_and_grad(w["eq"], net, x[:2000], t[:2000])  # warm-up
+    torch_ref.loss_f_and_grad(w["eq"], net, x[:2000], t[:2000])  # warm-ups
+    torch_ref.loss_f_and_grad(w["eq"], net, x, t)
     times = []
     t_start = time.time()
-    while len(times) < 8 and (time.time() - t_start) < budget_s:
+    while len(times) < 8 and (len(times) < 3 or (time.time() - t_start) < budget_s):
         t0 = time.time()
         torch_ref.loss_f_and_grad(w["eq"], net, x, t)
         times.append(time.time() - t0)
     per = float(np.median(times))
     out = {"value": n / per, "unit": "collocation evals/s", "cores": cores, "kind": "port",
-           "sample": "median of %d closures of nested-autograd net_f+backward at N=%d (oracle/torch_ref.py, fp32, torch CPU; "
-                     "fastest %.3e, slowest %.3e evals/s)" % (len(times), n, n / min(times), n / max(times))}
+           "sample": "median of %d closures (after 2 warm-ups) of nested-autograd net_f+backward at N=%d (oracle/torch_ref.py, fp32, "
+                     "torch CPU; fastest %.3e, slowest %.3e evals/s)" % (len(times), n, n / min(times), n / max(times))}
     # the C Taylor-jet oracle (same algorithm as the kernels) on the same cores, for context
     try:
         from oracle.pyoracle import Oracle
@@ -79,10 +99,13 @@ def cpu_baseline(w, budget_s=25.0):
         n2 = 100_000
         X2 = (lb + (ub - lb) * rng.random((n2, 2))).astype(np.float32)
         o.loss_grad(th, Xn[:1000, 0], Xn[:1000, 1], dtype=np.float32)
-        t0 = time.time()
-        o.loss_grad(th, X2[:, 0], X2[:, 1], scale=1.0 / n2, dtype=np.float32)
-        out["jet_c_port_value"] = n2 / (time.time() - t0)
-        out["jet_c_port_sample"] = "1 closure of the C Taylor-jet oracle (OpenMP, fp32) at N=%d" % n2
+        tj = []
+        for _ in range(3):
+            t0 = time.time()
+            o.loss_grad(th, X2[:, 0], X2[:, 1], scale=1.0 / n2, dtype=np.float32)
+            tj.append(time.time() - t0)
+        out["jet_c_port_value"] = n2 / float(np.median(tj))
+        out["jet_c_port_sample"] = "median of 3 closures of the C Taylor-jet oracle (OpenMP, fp32) at N=%d" % n2
     except Exception as ex:  # the oracle is optional for the bench
         out["jet_c_port_value"] = None
         out["jet_c_port_sample"] = "unavailable: %s" % ex
@@ -98,6 +121,9 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override points per GPU")
     ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--weights", default="ckpt", choices=["ckpt", "xavier"],
+                    help="ckpt: the reference's shipped checkpoint where one of the workload's shape exists "
+                         "(tests/golden fixture; SURVEY 8(d)), else xavier; xavier: xavier-normal, seed 1234")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: the workload's points PER GPU; strong: the workload's points IN TOTAL "
@@ -156,6 +182,12 @@ def main():
     cls = type("BenchPINN", (cls,), {"kernel": {"auto": 0, "valu": 1, "mfma": 2}[args.kernel]})
     torch.manual_seed(1234)            # identical xavier weights on every rank
     model = cls(w["layers"], np.array(w["lb"]), np.array(w["ub"]), process_group=group)
+    theta_ck = checkpoint_theta(w) if args.weights == "ckpt" else None
+    weights_desc = "xavier-normal weights seed 1234"
+    if theta_ck is not None:
+        with torch.no_grad():
+            model.dnn.flat_theta().copy_(torch.from_numpy(theta_ck))
+        weights_desc = "weights of the reference's shipped checkpoint (tests/golden/%s.npz)" % w["ckpt"]
     rng = np.random.default_rng(1234 + rank)
     lb, ub = np.array(w["lb"]), np.array(w["ub"])
     Xf = (lb + (ub - lb) * rng.random((n_local, 2))).astype(np.float32)
@@ -178,7 +210,11 @@ def main():
     def step():
         for p in model.dnn.parameters():
             p.grad = None
-        loss_f = model.loss_f()       # fused kernel pass (+ all-reduce when sharded)
+        if world > 1:
+            # the sharded training closure itself (pde_amd/pinn.py::_loss_terms_sharded), minus the data terms:
+            # fused kernel pass into the packed buffer, ONE all-reduce on RCCL, gradient handed to .grad
+            return model._loss_terms_sharded(data_terms=False)["loss_f"]
+        loss_f = model.loss_f()       # fused kernel pass
         loss_f.backward()             # hands the gradient to .grad (P-vector ops)
         return loss_f
 
@@ -211,7 +247,7 @@ def main():
     allreduce_us = None
     if world > 1:
         eng0 = model.engine_f
-        msg = torch.zeros(eng0.P + eng0.nf, device=dev)
+        msg = torch.zeros(eng0.P + model._T_SIZE, device=dev)     # the closure's packed buffer
         for _ in range(5):
             dist.all_reduce(msg)
         sync()
@@ -286,12 +322,12 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (uniform collocation points, xavier-normal weights seed 1234)"
+            "data": "synthetic (uniform collocation points, %s)" % weights_desc
                     + ("" if backend == "nccl" else " - REHEARSAL over %s, not a measurement" % backend),
             "config": {"workload": w["name"], "equation": w["eq"], "layers": w["layers"],
                        "points_per_gpu": n_local, "points_total": n_global, "scaling": args.scaling,
                        "parallelism": "dp%d over collocation points" % world,
-                       "kernel": {1: "valu", 2: "mfma"}[eng.kernel_kind]},
+                       "weights": weights_desc, "kernel": {1: "valu", 2: "mfma"}[eng.kernel_kind]},
             "allreduce_us": allreduce_us,
             "train_steps_per_s": train_sps,
             "train_hip_graph": graph_info,
@@ -300,11 +336,13 @@ def main():
                          "kernel_ms": 1e3 * k_avg,
                          "algorithmic_flops_per_point": FLOPS_PER_POINT[w["eq"]],
                          "note": "FP32 compute roofline (vector == f32-input MFMA peak); "
-                                 "algorithmic HBM traffic is 8 B/point (x, t in); `traffic` is the measured "
-                                 "per-launch HBM bytes, almost all of it the per-wave jet stash (DESIGN.md)"},
+                                 "algorithmic HBM traffic is 8 B/point (x, t in); `traffic` = HBM bytes per launch "
+                                 "looked up in profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                 "passes of this workload, not measured in this run; null if this size was not "
+                                 "profiled), almost all of it the per-wave jet stash (DESIGN.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w)
+            line["cpu_baseline"] = cpu_baseline(w, theta_ck)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if world > 1:

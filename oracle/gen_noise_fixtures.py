@@ -30,6 +30,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from gen_golden import OUT, REF, flat_grad, flat_theta, load_script, set_dtype  # noqa: E402
 
 NB, B = 12, 256
+# Camassa-Holm: the errors are heavy-tailed (a handful of points at the crest of the peakon, where u_xxt ~ 1500
+# cancels against u u_xxx, carry most of the sum of squares: on 12 batches ONE point held 71 % of it), so the
+# ratio of two RMS errors over 12 batches swings by 2x with rounding luck; 48 batches settle it to ~10 %.
+NB_CASE = {"ch_ckpt": 48}
 L50 = [2, 50, 50, 50, 50, 1]
 CASES = [
     # name, eq, script, class, layers, lb, ub, checkpoint
@@ -48,8 +52,13 @@ CASES = [
 
 
 def main():
+    global NB
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for name, eq, script, layers, lb, ub, ckpt in CASES:
+        if only and name not in only:
+            continue
+        NB = NB_CASE.get(name, 12)
         mod = load_script(script)
         lb, ub = np.array(lb), np.array(ub)
         mod.lb, mod.ub = lb, ub

@@ -37,22 +37,36 @@ int orc_orders(const orc_desc *d, int *K, int *KT, int *nf)
     return 0;
 }
 
-#define REAL float
-#define SFX(n) n##_f32
-#define TANH tanhf
-#define SQRT_ sqrtf
-#include "pinn_oracle_impl.h"
-#undef REAL
-#undef SFX
-#undef TANH
-#undef SQRT_
+/* Model of the kernels' "precise top" arithmetic (pde_amd/csrc, EqTraits<EQ>::PRECISE), for the float
+ * instantiation only: the dot products of the LAST hidden Linear layer (jet components 0, 1 and K+1: the
+ * pre-activation's value, x-slope and t-slope) and of the output layer (all components) are accumulated in
+ * double (their results are still stored as float) and the residual polynomial is evaluated in double.  Everything
+ * else stays float.  Off by default: orc_*_f32 is then the plain float restatement. */
+static int orc_f32_precise_top = 0;
+void orc_set_f32_precise_top(int on) { orc_f32_precise_top = on; }
 
 #define REAL double
 #define SFX(n) n##_f64
 #define TANH tanh
 #define SQRT_ sqrt
+#define ORC_TOP_ACC 0
 #include "pinn_oracle_impl.h"
 #undef REAL
 #undef SFX
 #undef TANH
 #undef SQRT_
+#undef ORC_TOP_ACC
+
+#define REAL float
+#define SFX(n) n##_f32
+#define TANH tanhf
+#define SQRT_ sqrtf
+#define ORC_TOP_ACC orc_f32_precise_top
+#define ORC_IS_F32 1
+#include "pinn_oracle_impl.h"
+#undef REAL
+#undef SFX
+#undef TANH
+#undef SQRT_
+#undef ORC_TOP_ACC
+#undef ORC_IS_F32

@@ -28,6 +28,9 @@ typedef struct {
 } orc_desc;
 
 int orc_orders(const orc_desc *d, int *K, int *KT, int *nf);
+/* float instantiation only: accumulate the last hidden Linear layer and the output layer in double and evaluate
+ * the residual polynomial in double (model of the kernels' EqTraits<EQ>::PRECISE arithmetic); 0 = plain float */
+void orc_set_f32_precise_top(int on);
 
 int orc_forward_f32(const orc_desc *d, const float *theta, const float *x, const float *t,
                     long n, float *derivs_out, float *f_out);

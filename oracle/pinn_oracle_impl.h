@@ -236,6 +236,24 @@ static void SFX(residual)(const orc_desc *d, int K, int KT,
     }
 }
 
+/* f from the output derivatives: the plain polynomial, or (precise-top model, float instantiation) the double
+ * polynomial on the double-accumulated output layer, rounded to float once */
+static void SFX(residual_top)(const orc_desc *d, int K, int KT,
+                              REAL D[ORC_MAXOUT][ORC_MAXJ], REAL T[ORC_MAXOUT][ORC_MAXJ],
+                              double Dd[ORC_MAXOUT][ORC_MAXJ], double Td[ORC_MAXOUT][ORC_MAXJ], REAL *f)
+{
+#ifdef ORC_IS_F32
+    if (ORC_TOP_ACC && d->n_lin >= 2) {
+        double fd[ORC_MAXF] = {0, 0, 0};
+        residual_f64(d, K, KT, Dd, Td, fd, NULL, NULL, NULL);
+        for (int c = 0; c < ORC_MAXF; ++c) f[c] = (REAL)fd[c];
+        return;
+    }
+#endif
+    (void)Dd; (void)Td;
+    SFX(residual)(d, K, KT, D, T, f, NULL, NULL, NULL);
+}
+
 /* ---- per-point forward through the whole net ------------------------------
  * work layout: for every linear layer l the input jets A_l[i][j] (i<in_l,
  * j<J) and pre-activation jets Z_l[o][j]; J = K+1+KT, components
@@ -251,7 +269,8 @@ typedef struct {
 
 static void SFX(point_forward)(const orc_desc *d, int K, int KT, const REAL *theta,
                                REAL x, REAL t, SFX(orc_work) *wk,
-                               REAL D[ORC_MAXOUT][ORC_MAXJ], REAL T[ORC_MAXOUT][ORC_MAXJ])
+                               REAL D[ORC_MAXOUT][ORC_MAXJ], REAL T[ORC_MAXOUT][ORC_MAXJ],
+                               double Dd[ORC_MAXOUT][ORC_MAXJ], double Td[ORC_MAXOUT][ORC_MAXJ])
 {
     const int J = K + 1 + KT;
     const REAL lbx = (REAL)d->lb[0], lbt = (REAL)d->lb[1];
@@ -270,11 +289,27 @@ static void SFX(point_forward)(const orc_desc *d, int K, int KT, const REAL *the
         p = b + nout;
         const REAL *a = wk->A[l];
         REAL *z = wk->Z[l];
+        /* (precise-top model: the last hidden Linear layer and the output layer accumulate in double) */
+        const int top_acc = ORC_TOP_ACC && l >= d->n_lin - 2 && l >= 1;
         for (int o = 0; o < nout; ++o) {
             for (int j = 0; j < J; ++j) {
-                REAL s = (j == 0) ? b[o] : (REAL)0;
-                for (int i = 0; i < nin; ++i) s += W[(size_t)o * nin + i] * a[i * J + j];
-                z[o * J + j] = s;
+                /* last hidden layer: only the value, the first x-derivative and the first t-derivative of the
+                 * pre-activation (the kernels' choice, kernel_mfma.hpp); output layer: every component */
+                if (top_acc && (l == d->n_lin - 1 || j == 0 || j == 1 || j == K + 1)) {
+                    double s = (j == 0) ? (double)b[o] : 0.0;
+                    for (int i = 0; i < nin; ++i) s += (double)W[(size_t)o * nin + i] * (double)a[i * J + j];
+                    z[o * J + j] = (REAL)s;
+                    if (l == d->n_lin - 1 && Dd) {
+                        double fact = 1;
+                        const int k = j <= K ? j : j - K - 1;
+                        for (int q = 2; q <= k; ++q) fact *= q;
+                        if (j <= K) Dd[o][k] = fact * s; else Td[o][k] = fact * s;
+                    }
+                } else {
+                    REAL s = (j == 0) ? b[o] : (REAL)0;
+                    for (int i = 0; i < nin; ++i) s += W[(size_t)o * nin + i] * a[i * J + j];
+                    z[o * J + j] = s;
+                }
             }
         }
         if (l < d->n_lin - 1) {
@@ -390,14 +425,15 @@ int SFX(orc_forward)(const orc_desc *d, const REAL *theta, const REAL *x, const 
         REAL D[ORC_MAXOUT][ORC_MAXJ], T[ORC_MAXOUT][ORC_MAXJ], f[ORC_MAXF];
 #pragma omp for schedule(static)
         for (long p = 0; p < n; ++p) {
-            SFX(point_forward)(d, K, KT, theta, x[p], t[p], &wk, D, T);
+            double Dd[ORC_MAXOUT][ORC_MAXJ], Td[ORC_MAXOUT][ORC_MAXJ];
+            SFX(point_forward)(d, K, KT, theta, x[p], t[p], &wk, D, T, Dd, Td);
             if (derivs_out)
                 for (int o = 0; o < nout; ++o) {
                     for (int k = 0; k <= K; ++k) derivs_out[((size_t)p * nout + o) * J + k] = D[o][k];
                     for (int k = 0; k < KT; ++k) derivs_out[((size_t)p * nout + o) * J + K + 1 + k] = T[o][k];
                 }
             if (f_out) {
-                SFX(residual)(d, K, KT, D, T, f, NULL, NULL, NULL);
+                SFX(residual_top)(d, K, KT, D, T, Dd, Td, f);
                 for (int c = 0; c < nf; ++c) f_out[(size_t)p * nf + c] = f[c];
             }
         }
@@ -445,8 +481,9 @@ int SFX(orc_loss_grad)(const orc_desc *d, const REAL *theta, const REAL *x, cons
         REAL Db[ORC_MAXOUT][ORC_MAXJ], Tb[ORC_MAXOUT][ORC_MAXJ];
 #pragma omp for schedule(static)
         for (long p = 0; p < n; ++p) {
-            SFX(point_forward)(d, K, KT, theta, x[p], t[p], &wk, D, T);
-            SFX(residual)(d, K, KT, D, T, f, NULL, NULL, NULL);
+            double Dd[ORC_MAXOUT][ORC_MAXJ], Td[ORC_MAXOUT][ORC_MAXJ];
+            SFX(point_forward)(d, K, KT, theta, x[p], t[p], &wk, D, T, Dd, Td);
+            SFX(residual_top)(d, K, KT, D, T, Dd, Td, f);
             for (int c = 0; c < nf; ++c) {
                 if (gbar) fb[c] = gbar[(size_t)p * nf + c];
                 else { fb[c] = (REAL)(2.0 * scale) * f[c]; ls[c] += (double)f[c] * (double)f[c]; }

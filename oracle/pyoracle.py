@@ -61,6 +61,12 @@ def lib():
     return _lib
 
 
+def set_f32_precise_top(on):
+    """float32 entry points only: model the kernels' "precise top" arithmetic (last hidden Linear layer, output
+    layer and residual polynomial accumulated / evaluated in double; pinn_oracle.c).  Process-wide switch."""
+    lib().orc_set_f32_precise_top(ctypes.c_int(1 if on else 0))
+
+
 class Oracle:
     """One network + equation.  layers: the script's `layers` list; lb/ub are
     rounded to float32 first because the reference's Scale stores them as

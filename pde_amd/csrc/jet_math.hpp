@@ -15,15 +15,28 @@ namespace pinn {
 enum { EQ_NONE = 0, EQ_BURGERS = 1, EQ_KDV5 = 2, EQ_KDV7 = 3, EQ_CH = 4, EQ_GNSS = 5, EQ_LPD = 6, EQ_NLSREG = 7 };
 
 template <int EQ> struct EqTraits;
-// NF = residual components per point (0: as many as the net has outputs)
-template <> struct EqTraits<EQ_NONE>    { static constexpr int K = 0, KT = 0, NF = 0; };
-template <> struct EqTraits<EQ_BURGERS> { static constexpr int K = 2, KT = 1, NF = 1; };
-template <> struct EqTraits<EQ_KDV5>    { static constexpr int K = 5, KT = 1, NF = 1; };
-template <> struct EqTraits<EQ_KDV7>    { static constexpr int K = 7, KT = 1, NF = 1; };
-template <> struct EqTraits<EQ_CH>      { static constexpr int K = 3, KT = 3, NF = 1; };
-template <> struct EqTraits<EQ_GNSS>    { static constexpr int K = 3, KT = 1, NF = 2; };
-template <> struct EqTraits<EQ_LPD>     { static constexpr int K = 4, KT = 1, NF = 2; };
-template <> struct EqTraits<EQ_NLSREG>  { static constexpr int K = 2, KT = 1, NF = 3; };
+// NF = residual components per point (0: as many as the net has outputs); NOUT = most network outputs the
+// equation's nets can have (pinn_create checks the exact number)
+// PRECISE = "precise top": the dot products of the LAST hidden Linear layer and of the output layer are accumulated
+// in float64 (f64 MFMA / v_fma_f64; results stored as float32 like everything else) and the residual polynomial is
+// evaluated in float64.  For Camassa-Holm: f = (u - u_xx)_t + ... is a cancellation of u_xxt against u u_xxx
+// (~1500 against ~1400 at the crest of the trained peakon) whose two sides come out of DIFFERENT jet components,
+// i.e. different float32 dot products with independent rounding errors, while the reference's nested-autograd
+// graph perturbs both consistently.  Stage by stage (tools/ch_noise_lab.py) the excess noise
+// sits in exactly those late dot products: made exact, the residual / loss / gradient noise at CH/model/PINN CH.pth
+// falls from 3.4x / 4.8x / 5.7x the reference's own fp32 noise to 1.3x / 1.5x / 1.5x (96 batches of 256 points).
+// It is on for every residual: at the other seven shipped checkpoints it takes the noise from 0.7-1.8x the
+// reference's to 0.4-1.4x (profiles/r03_noise_report.txt) for 1-2 % of the kernel time (three of the J components of
+// one of nine GEMM phases at the f64 rate).  Off for plain net_u (EQ_NONE: nothing cancels) and, in the MFMA
+// kernels, for the wide shapes (width 100: no registers to spare, +10 % time; those nets sit at 0.9-1.2x anyway).
+template <> struct EqTraits<EQ_NONE>    { static constexpr int K = 0, KT = 0, NF = 0, NOUT = 2; static constexpr bool PRECISE = false; };
+template <> struct EqTraits<EQ_BURGERS> { static constexpr int K = 2, KT = 1, NF = 1, NOUT = 1; static constexpr bool PRECISE = true; };
+template <> struct EqTraits<EQ_KDV5>    { static constexpr int K = 5, KT = 1, NF = 1, NOUT = 1; static constexpr bool PRECISE = true; };
+template <> struct EqTraits<EQ_KDV7>    { static constexpr int K = 7, KT = 1, NF = 1, NOUT = 1; static constexpr bool PRECISE = true; };
+template <> struct EqTraits<EQ_CH>      { static constexpr int K = 3, KT = 3, NF = 1, NOUT = 1; static constexpr bool PRECISE = true; };
+template <> struct EqTraits<EQ_GNSS>    { static constexpr int K = 3, KT = 1, NF = 2, NOUT = 2; static constexpr bool PRECISE = true; };
+template <> struct EqTraits<EQ_LPD>     { static constexpr int K = 4, KT = 1, NF = 2, NOUT = 2; static constexpr bool PRECISE = true; };
+template <> struct EqTraits<EQ_NLSREG>  { static constexpr int K = 2, KT = 1, NF = 3, NOUT = 2; static constexpr bool PRECISE = true; };
 
 constexpr int MAXOUT = 2;
 constexpr int MAXF = 3;     // residual components per point: two outputs + one penalty row (EQ_NLSREG)
@@ -178,14 +191,18 @@ __host__ __device__ constexpr float factorial(int k)
     return f;
 }
 
+__device__ __forceinline__ float sqrt_r(float v) { return sqrtf(v); }
+__device__ __forceinline__ double sqrt_r(double v) { return sqrt(v); }
+
 // ---- residuals ---------------------------------------------------------------
 // D[o][k] = d^k u_o/dx^k, T[o][k] = d/dt d^k u_o/dx^k (true derivatives).
-// eval() writes f[0..NF-1]; adj() accumulates fb[c]*df_c/d(.) into Db/Tb.
+// eval() writes f[0..NF-1] (in the arithmetic type R of its arguments: float, or double for the PRECISE
+// equations); adj() accumulates fb[c]*df_c/d(.) into Db/Tb.
 template <int EQ> struct Residual;
 
 template <> struct Residual<EQ_NONE> {  // plain net_u: f_o = u_o  (self.dnn(X), :99)
     static constexpr int K = 0, KT = 0;
-    template <class A> __device__ static void eval(const A &D, const A &, const float *, int nout, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &, const float *, int nout, R *f)
     {
         f[0] = D[0][0];
         if (nout > 1) f[1] = D[1][0];
@@ -200,9 +217,9 @@ template <> struct Residual<EQ_NONE> {  // plain net_u: f_o = u_o  (self.dnn(X),
 
 template <> struct Residual<EQ_BURGERS> {  // Burgers/Burgers_equation(PINN).py:126-131
     static constexpr int K = 2, KT = 1;
-    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &T, const float *c, int, R *f)
     {
-        const float *u = D[0];
+        const R *u = D[0];
         f[0] = T[0][0] + u[0] * u[1] - c[0] * u[2];
     }
     template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
@@ -219,9 +236,9 @@ template <> struct Residual<EQ_BURGERS> {  // Burgers/Burgers_equation(PINN).py:
 
 template <> struct Residual<EQ_KDV5> {  // 5kdv/PI-51.py:132-140
     static constexpr int K = 5, KT = 1;
-    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &T, const float *c, int, R *f)
     {
-        const float *u = D[0];
+        const R *u = D[0];
         f[0] = T[0][0] + c[0] * u[0] * u[0] * u[1] + c[1] * u[1] * u[2] + c[2] * u[0] * u[3] + c[3] * u[5];
     }
     template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
@@ -240,9 +257,9 @@ template <> struct Residual<EQ_KDV5> {  // 5kdv/PI-51.py:132-140
 
 template <> struct Residual<EQ_KDV7> {  // 7kdv/PI-7kdv3soliton.py:132, 7kdv/PI-7kdv1soliton.py:132
     static constexpr int K = 7, KT = 1;
-    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &T, const float *c, int, R *f)
     {
-        const float *u = D[0];
+        const R *u = D[0];
         f[0] = T[0][0] + c[0] * u[0] * u[0] * u[0] * u[1] + c[1] * u[1] * u[1] * u[1]
              + c[2] * u[0] * u[1] * u[2] + c[3] * u[0] * u[0] * u[3] + c[4] * u[2] * u[3]
              + c[5] * u[1] * u[4] + c[6] * u[0] * u[5] + c[7] * u[7];
@@ -265,9 +282,9 @@ template <> struct Residual<EQ_KDV7> {  // 7kdv/PI-7kdv3soliton.py:132, 7kdv/PI-
 
 template <> struct Residual<EQ_CH> {  // CH/PI-CH-1soliton.py:131-138; CH/bc-CH-1soliton.py:270-278 (c[0]=2)
     static constexpr int K = 3, KT = 3;
-    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &T, const float *c, int, R *f)
     {
-        const float *u = D[0];
+        const R *u = D[0];
         f[0] = T[0][0] - T[0][2] + 3.0f * u[0] * u[1] - 2.0f * u[2] * u[1] + c[0] * u[1] - u[3] * u[0];
     }
     template <class A> __device__ static void adj(const A &D, const A &, const float *c, int,
@@ -286,10 +303,10 @@ template <> struct Residual<EQ_CH> {  // CH/PI-CH-1soliton.py:131-138; CH/bc-CH-
 
 template <> struct Residual<EQ_GNSS> {  // NLS/sw-GNSS-adamW.py:159-180 (c[2]=0: NLS/sw-PINN-rogue.py:179-180)
     static constexpr int K = 3, KT = 1;
-    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &T, const float *c, int, R *f)
     {
-        const float *u = D[0], *v = D[1];
-        const float rho = u[0] * u[0] + v[0] * v[0];
+        const R *u = D[0], *v = D[1];
+        const R rho = u[0] * u[0] + v[0] * v[0];
         f[0] = T[0][0] + c[0] * v[2] + c[1] * rho * v[0] - c[2] * (u[3] + 6.0f * rho * u[1]);
         f[1] = T[1][0] - c[0] * u[2] - c[1] * rho * u[0] - c[2] * (v[3] + 6.0f * rho * v[1]);
     }
@@ -324,14 +341,14 @@ template <> struct Residual<EQ_GNSS> {  // NLS/sw-GNSS-adamW.py:159-180 (c[2]=0:
 // coef = [a, b, c3, c4, p, q] = [0.5, 1, 0.125, 0.0625, 6, 10].
 template <> struct Residual<EQ_LPD> {
     static constexpr int K = 4, KT = 1;
-    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &T, const float *c, int, R *f)
     {
-        const float *u = D[0], *v = D[1];
+        const R *u = D[0], *v = D[1];
         const float a = c[0], b = c[1], c3 = c[2], c4 = c[3], pp = c[4], qq = c[5];
-        const float rho = u[0] * u[0] + v[0] * v[0];
-        const float Gv = v[4] + 10.0f * v[0] * v[1] * v[1] - 2.0f * v[0] * u[1] * u[1] + 12.0f * u[0] * u[1] * v[1]
+        const R rho = u[0] * u[0] + v[0] * v[0];
+        const R Gv = v[4] + 10.0f * v[0] * v[1] * v[1] - 2.0f * v[0] * u[1] * u[1] + 12.0f * u[0] * u[1] * v[1]
                        + pp * rho * v[2] + 6.0f * rho * rho * v[0];
-        const float Gu = u[4] + 10.0f * u[0] * u[1] * u[1] - 2.0f * u[0] * v[1] * v[1] + 12.0f * v[0] * u[1] * v[1]
+        const R Gu = u[4] + 10.0f * u[0] * u[1] * u[1] - 2.0f * u[0] * v[1] * v[1] + 12.0f * v[0] * u[1] * v[1]
                        + qq * rho * u[2] + 6.0f * rho * rho * u[0];
         f[0] = T[0][0] + a * v[2] + b * rho * v[0] + c4 * Gv - c3 * (u[3] + 6.0f * rho * u[1]);
         f[1] = T[1][0] - a * u[2] - b * rho * u[0] - c4 * Gu - c3 * (v[3] + 6.0f * rho * v[1]);
@@ -377,14 +394,14 @@ template <> struct Residual<EQ_LPD> {
 // so that sum_c mean(f_c^2) is loss_f + reg_term and the same fused kernel serves it.  coef = [a, b, lambda].
 template <> struct Residual<EQ_NLSREG> {
     static constexpr int K = 2, KT = 1;
-    template <class A> __device__ static void eval(const A &D, const A &T, const float *c, int, float *f)
+    template <class A, class R> __device__ static void eval(const A &D, const A &T, const float *c, int, R *f)
     {
-        const float *u = D[0], *v = D[1];
-        const float rho = u[0] * u[0] + v[0] * v[0];
+        const R *u = D[0], *v = D[1];
+        const R rho = u[0] * u[0] + v[0] * v[0];
         f[0] = T[0][0] + c[0] * v[2] + c[1] * rho * v[0];
         f[1] = T[1][0] - c[0] * u[2] - c[1] * rho * u[0];
-        const float S = u[1] * u[1] + u[2] * u[2] + T[0][0] * T[0][0] + v[1] * v[1] + v[2] * v[2] + T[1][0] * T[1][0];
-        f[2] = sqrtf(c[2] * S);
+        const R S = u[1] * u[1] + u[2] * u[2] + T[0][0] * T[0][0] + v[1] * v[1] + v[2] * v[2] + T[1][0] * T[1][0];
+        f[2] = sqrt_r(c[2] * S);
     }
     template <class A> __device__ static void adj(const A &D, const A &T, const float *c, int,
                                                   const float *fb, A &Db, A &Tb)

@@ -49,6 +49,7 @@ template <int EQ, int MODE>
 __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float *scratch)
 {
     constexpr int K = EqTraits<EQ>::K, KT = EqTraits<EQ>::KT, J = K + 1 + KT;
+    constexpr bool PRECISE = EqTraits<EQ>::PRECISE;      // jet_math.hpp: float64 accumulation in the top two Linear layers
     extern __shared__ float lds_g[];  // [P+2] workgroup partial of (grad, loss sums)
     const int P = d.P;
     if (MODE != MODE_FWD) {
@@ -86,13 +87,46 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
         }
 
         // ---- forward through the layers ----
+        double ud[MAXOUT][J];      // PRECISE: the output layer's float64 sums (the residual polynomial takes them as they are)
+#pragma unroll
+        for (int o = 0; o < MAXOUT; ++o)
+#pragma unroll
+            for (int j = 0; j < J; ++j) ud[o][j] = 0.0;
         for (int l = 0; l < d.n_lin; ++l) {
             const int nin = d.widths[l], no = d.widths[l + 1];
             const float *W = a.theta + d.woff[l], *B = a.theta + d.boff[l];
             const int in_slot = (l == 0) ? sl.ain : sl.y[l - 1];
             const bool hidden = l < d.n_lin - 1;
+            const bool top = PRECISE && l >= 1 && l >= d.n_lin - 2;
             for (int o0 = 0; o0 < no; o0 += VALU_OB) {
                 float acc[VALU_OB][J];
+                if (PRECISE && top) {
+                    double accd[VALU_OB][J];
+#pragma unroll
+                    for (int ob = 0; ob < VALU_OB; ++ob) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j) accd[ob][j] = 0.0;
+                        accd[ob][0] = (o0 + ob < no) ? (double)B[o0 + ob] : 0.0;
+                    }
+                    for (int i = 0; i < nin; ++i) {
+                        double av[J];
+#pragma unroll
+                        for (int j = 0; j < J; ++j) av[j] = (double)SL(in_slot + i * J + j);
+#pragma unroll
+                        for (int ob = 0; ob < VALU_OB; ++ob) {
+                            const double w = (o0 + ob < no) ? (double)W[(o0 + ob) * nin + i] : 0.0;
+#pragma unroll
+                            for (int j = 0; j < J; ++j) accd[ob][j] = fma(w, av[j], accd[ob][j]);
+                        }
+                    }
+#pragma unroll
+                    for (int ob = 0; ob < VALU_OB; ++ob)
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            acc[ob][j] = (float)accd[ob][j];
+                            if (!hidden && o0 + ob < MAXOUT) ud[(o0 + ob) < MAXOUT ? o0 + ob : 0][j] = accd[ob][j];
+                        }
+                } else {
 #pragma unroll
                 for (int ob = 0; ob < VALU_OB; ++ob) {
 #pragma unroll
@@ -109,6 +143,7 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
 #pragma unroll
                         for (int j = 0; j < J; ++j) acc[ob][j] = fmaf(w, av[j], acc[ob][j]);
                     }
+                }
                 }
 #pragma unroll
                 for (int ob = 0; ob < VALU_OB; ++ob) {
@@ -138,7 +173,23 @@ __global__ __launch_bounds__(VALU_BLOCK) void k_valu(KDesc d, CallArgs a, float 
             for (int k = 0; k < KT; ++k) T[o][k] = (o < nout) ? factorial(k) * SL(zl + o * J + K + 1 + k) : 0.0f;
         }
         float f[MAXF] = {0.0f, 0.0f, 0.0f};
-        Residual<EQ>::eval(D, T, d.coef, nout, f);
+        if (PRECISE) {
+            double Dd[MAXOUT][J], Td[MAXOUT][J], fd[MAXF] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int o = 0; o < MAXOUT; ++o) {
+#pragma unroll
+                for (int j = 0; j < J; ++j) { Dd[o][j] = 0.0; Td[o][j] = 0.0; }
+#pragma unroll
+                for (int k = 0; k <= K; ++k) Dd[o][k] = (double)factorial(k) * ud[o][k];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) Td[o][k] = (double)factorial(k) * ud[o][K + 1 + k];
+            }
+            Residual<EQ>::eval(Dd, Td, d.coef, nout, fd);
+#pragma unroll
+            for (int c = 0; c < MAXF; ++c) f[c] = (float)fd[c];
+        } else {
+            Residual<EQ>::eval(D, T, d.coef, nout, f);
+        }
 
         if (MODE == MODE_FWD) {
             if (valid) {

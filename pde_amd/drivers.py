@@ -154,41 +154,48 @@ def sliding_window(model_cls, layers, x, t, exact_u, *, num_windows=3, window_fr
 
 def backward_compatible(pi_cls, bc_cls, layers, x, t, exact_u, *, step=50, N0=100, Nf=20000, nIter=5000,
                         LBFGS_max_iter=50000, model_name="model_segment_{seg}.pth",
-                        log_name="log-bc{seg}.txt", rng=None, reference_quirks=False):
+                        log_name="log-bc{seg}.txt", rng=None, corrected=False):
     """Backward-compatible (bc-PINN) training over consecutive time segments,
-    ``CH/bc-CH-1soliton.py:378-473`` (same loop in ``7kdv/bc-7kdv*.py``, ``5kdv/bc-5*.py``).
+    ``CH/bc-CH-1soliton.py:378-473`` (the same loop is commented out in ``7kdv/bc-7kdv*.py``, ``5kdv/bc-5*.py``).
 
     The time grid is cut into segments of ``step`` rows (one row of overlap).  Segment 0 trains the
     plain PI class on ``[t_0, t_seg_end]`` from the data's initial condition.  Every later segment
-    trains the bc class on the domain grown to its right edge: initial condition = the previous
-    model's prediction on the segment's first row, plus the retention term ``loss1`` over the whole
-    history grid ``Xh`` (all rows up to the previous right edge) labelled by the previous model.
+    trains the bc class on the domain grown to its right edge, with the retention term ``loss1`` over the
+    whole history grid ``Xh`` (all rows up to the previous right edge) labelled by the previous model.
     Returns ``(models, u1)`` with ``u1`` the last model's prediction on the final history grid.
 
-    ``reference_quirks``: two things the reference does that look unintended and are NOT reproduced by
-    default: (i) it passes the segment's first ROW INDEX as ``t0`` to ``set_training_data``
-    (``:443-445``) although the argument is a time — default here: the time value ``t[t1]``; (ii) it
-    pairs the random ``x0`` with ``u1[-N0:]``, the last N0 grid values of the history prediction
-    (``:442``), not with the prediction at those ``x0`` — default here: the previous model's values at
-    ``x0`` on the segment's first row.  ``reference_quirks=True`` reproduces both."""
+    By default every argument handed to the classes is what the reference's loop hands over
+    (tests/golden/bc_driver_args.npz: a replay of ``:334-473`` on synthetic data; tests/test_drivers_cpu.py),
+    including three things that look unintended:
+      (i)   later segments get the segment's first ROW INDEX as ``t0`` (``:447-448``) although the argument is a
+            time (50, 100, 150 on a grid whose times run from -1 to 1);
+      (ii)  and ``u0 = u1[-N0:]`` (``:446``), the last N0 grid values of the history prediction, paired with the
+            random ``x0`` of segment 0;
+      (iii) the loop ends where the reference's run ends: at the first segment with fewer than ``step/2`` time rows
+            (``np.random.choice(rows, Nb, replace=False)`` raises there: after four segments on a 201-row grid).
+    ``corrected=True`` instead passes the TIME of the segment's first row as ``t0``, the previous model's values at
+    ``x0`` on that row as ``u0``, and trains a short last segment on the rows it has.
+    ``rng``: a ``numpy.random.Generator``, or the ``numpy.random`` module itself for the reference's global-state
+    draws (after ``np.random.seed(1234)``, ``:21``); draws are made in the reference's order."""
     rng = np.random.default_rng(1234) if rng is None else rng
     nt = t.shape[0]
     steps_lb = np.arange(0, nt + step, step)
     steps_ub = 1 + steps_lb
     idx = rng.choice(x.shape[0], N0, replace=False)
     x0 = x[idx, :]
-    u0 = exact_u[0, :].reshape(-1, 1)[idx, :]
+    u0 = exact_u[0:1, :].T[idx, :]
     Nb = int(step / 2)
     models, u1, Xh = [], None, None
     x_lo, x_hi = float(x.min()), float(x.max())
     t_start = float(t.min())
     for seg in range(steps_lb.size - 1):
-        t1, t2 = int(steps_lb[seg]), int(min(steps_ub[seg + 1], nt))
-        if t1 >= nt - 1:
-            break
-        t_seg = t[t1:t2, :]
+        t1, t2 = int(steps_lb[seg]), int(steps_ub[seg + 1])
         temp_t = t[:t2, :]
-        tb = t_seg[rng.choice(t_seg.shape[0], min(Nb, t_seg.shape[0]), replace=False), :]
+        t_seg = t[t1:t2, :]
+        rows = t_seg.shape[0]
+        if rows < (2 if corrected else Nb):
+            break
+        tb = t_seg[rng.choice(rows, min(Nb, rows), replace=False), :]
         lb = np.array([x_lo, t_start])
         ub = np.array([x_hi, float(np.max(t_seg))])
         seg_lb = np.array([x_lo, float(np.min(t_seg))])
@@ -198,11 +205,11 @@ def backward_compatible(pi_cls, bc_cls, layers, x, t, exact_u, *, step=50, N0=10
             model = pi_cls(layers, lb, ub)
             model.set_training_data(x0, u0, tb, Xf)
         else:
-            if reference_quirks:
-                u0, t0 = u1[-N0:], float(t1)
-            else:
+            if corrected:
                 u0 = u1[-x.shape[0]:][idx, :]      # previous model on the segment's first row (= last history row)
                 t0 = float(t[t1, 0])
+            else:
+                u0, t0 = u1[-N0:], t1
             model = bc_cls(layers, lb, ub)
             model.set_training_data(x0, u0, t0, u1, tb, Xf, Xh)
         model.train(nIter, log_name.format(seg=seg) if log_name else None, LBFGS_max_iter=LBFGS_max_iter)

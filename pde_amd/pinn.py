@@ -75,7 +75,7 @@ class PhysicsInformedNN:
     base_dir = os.getcwd()           # where model/ and log/ live (<script dir> in the reference)
     default_device = None            # None -> current CUDA device
     kernel = KERNEL_AUTO
-    use_hip_graph = False            # train(): replay the Adam phase from a captured HIP graph (single process)
+    use_hip_graph = False            # train(): replay the Adam phase / the L-BFGS closure from a captured HIP graph
     # eager backward(): the collocation kernel on a second stream beside the data-term chain.  None = automatic:
     # only when that kernel is long enough to pay for the extra host work of two streams (measured at 20 000
     # points: GNSS width 100 +20 % closures/s, width-50 nets -20 %: their eager closures are host-bound)
@@ -657,7 +657,7 @@ class PhysicsInformedNN:
             self.writer.write("Start Training:", mode='w')
         start_time = time.time()
         done = 0
-        if self.use_hip_graph and nIter > 16 and self.group is None and torch.device(self.device).type == "cuda":
+        if self.use_hip_graph and nIter > 16 and self._graph_capturable():
             done = self._train_adam_graph(nIter, params)
         for _ in range(nIter - done):
             self.optimizer_Adam.zero_grad()
@@ -669,8 +669,7 @@ class PhysicsInformedNN:
             return self.backward()
         # (the reference always makes this call, :161 - with LBFGS_max_iter = 0 torch evaluates the closure once)
         closure = LBFGS_callback
-        if LBFGS_max_iter > 0 and self.use_hip_graph and self.group is None and torch.device(self.device).type == "cuda" \
-                and hasattr(self.optimizer_LBFGS, "flat_grad"):
+        if LBFGS_max_iter > 0 and self.use_hip_graph and self._graph_capturable() and hasattr(self.optimizer_LBFGS, "flat_grad"):
             closure = self._graph_closure() or LBFGS_callback
         if hasattr(self.optimizer_LBFGS, "on_discard"):
             def _undo_iteration():      # a speculative evaluation pde_amd.lbfgs.LBFGS made in vain: not an iteration
@@ -682,6 +681,17 @@ class PhysicsInformedNN:
             self.writer.write('Training time: %.4f' % (elapsed))
         if self._is_rank0():
             print('Training time: %.4f' % (elapsed))
+
+    def _graph_capturable(self):
+        """Can a closure of this model be captured into a HIP graph?  A single-process run always; a sharded run
+        when its closure is the direct form (no autograd graph) and its collective runs on RCCL, whose all-reduce
+        is captured like any kernel (tests/test_gpu_rccl.py).  A gloo group (host-staged buffer) cannot."""
+        if torch.device(self.device).type != "cuda":
+            return False
+        if self.group is None:
+            return True
+        import torch.distributed as dist
+        return self.closure_impl == "direct" and dist.get_backend(self.group) == "nccl"
 
     def _train_adam_graph(self, nIter, params):
         """the Adam phase without per-iteration host work.  One whole iteration

@@ -126,6 +126,20 @@ def main():
                          evals=opt.state[opt._params[0]]["func_evals"], module=type(opt).__module__,
                          finite=bool(torch.isfinite(m.dnn.flat_theta()).all()))
     ms.check_replicas()
+    # the same training from captured HIP graphs: the Adam iteration and the L-BFGS closure, each with the RCCL
+    # all-reduce INSIDE the graph
+    mg = make(dist.group.WORLD)
+    mg.use_hip_graph = True
+    mg.train(n_adam, LBFGS_max_iter=0)
+    res["graph_replays"] = getattr(mg, "graph_stats", {}).get("replays", 0)
+    th_g = mg.dnn.flat_theta().detach().cpu().double().numpy().copy()
+    res["adam_graph_theta_rel"] = float(np.linalg.norm(th_g - out["sharded"]["th_adam"]) / np.linalg.norm(th_g))
+    mg.train(0, init_iter=mg.iter, LBFGS_max_iter=n_lbfgs)
+    res["lbfgs_graph_captured"] = hasattr(mg, "_lbfgs_graph")
+    for p in mg.dnn.parameters():
+        p.grad = None
+    res["loss_end_graph"] = mg._loss_terms()["loss"].item()
+    mg.check_replicas()
     a, b = out["sharded"], out["single"]
     res["adam_theta_rel"] = float(np.linalg.norm(a["th_adam"] - b["th_adam"]) / np.linalg.norm(b["th_adam"]))
     res["loss_adam"] = [a["l_adam"], b["l_adam"]]

@@ -75,16 +75,90 @@ def test_backward_compatible_segments(tmp_path):
     pi = install(scripts.kdv5_1soliton.PI.PhysicsInformedNN)
     bc = install(scripts.kdv5_1soliton.bc.bcPhysicsInformedNN)
     pi.base_dir = bc.base_dir = str(tmp_path)
-    models, u1 = drivers.backward_compatible(pi, bc, [2, 6, 6, 1], x, t, exact, step=10, N0=10, Nf=40, nIter=2,
-                                             LBFGS_max_iter=0, log_name=None, rng=np.random.default_rng(0))
-    # 21 time rows, segments of 10 rows (+1 row overlap): rows [0,11), [10,21), then the grid is exhausted
-    assert len(models) == 2
-    assert type(models[0]).__name__ == "PhysicsInformedNN" and type(models[1]).__name__ == "bcPhysicsInformedNN"
-    assert np.isclose(models[0].ub[1], t[10, 0]) and np.isclose(models[1].ub[1], t[20, 0])
-    assert np.isclose(models[1].lb[1], t[0, 0])                                  # the domain grows, it does not slide
-    assert models[1].x1.shape[0] == 11 * 24                                      # history grid = rows 0..10
-    assert np.isclose(float(models[1].t0[0, 0]), t[10, 0])                       # IC pinned at the segment's left edge
-    assert u1.shape == (21 * 24, 1)
+    for corrected in (False, True):
+        models, u1 = drivers.backward_compatible(pi, bc, [2, 6, 6, 1], x, t, exact, step=10, N0=10, Nf=40, nIter=2,
+                                                 LBFGS_max_iter=0, log_name=None, rng=np.random.default_rng(0),
+                                                 corrected=corrected)
+        # 21 time rows, segments of 10 rows (+1 row overlap): rows [0,11), [10,21), then one row is left: the
+        # reference's loop stops there (fewer rows than Nb), and so does the corrected one (a single row)
+        assert len(models) == 2
+        assert type(models[0]).__name__ == "PhysicsInformedNN" and type(models[1]).__name__ == "bcPhysicsInformedNN"
+        assert np.isclose(models[0].ub[1], t[10, 0]) and np.isclose(models[1].ub[1], t[20, 0])
+        assert np.isclose(models[1].lb[1], t[0, 0])                                  # the domain grows, it does not slide
+        assert models[1].x1.shape[0] == 11 * 24                                      # history grid = rows 0..10
+        # the reference pins the IC at the segment's first ROW INDEX (CH/bc-CH-1soliton.py:447-448); corrected: its time
+        assert np.isclose(float(models[1].t0[0, 0]), t[10, 0] if corrected else 10.0)
+        assert u1.shape == (21 * 24, 1)
+
+
+def _stub_predict(X, seg):
+    X = np.asarray(X, dtype=np.float64)
+    return (np.sin(0.3 * X[:, 0:1] + 0.1 * seg) * np.cos(1.7 * X[:, 1:2]) + 0.05 * seg).astype(np.float64)
+
+
+def test_backward_compatible_hands_over_what_the_reference_does():
+    """pde_amd.drivers.backward_compatible against tests/golden/bc_driver_args.npz: the arguments the REFERENCE's own
+    loop (CH/bc-CH-1soliton.py:334-473, replayed by oracle/gen_bc_driver_fixture.py on a synthetic 201 x 128
+    travelling wave with train/save as no-ops and predict in closed form) hands to its classes, segment by segment:
+    class, lb, ub, x0, u0, t0 (the row index 50 / 100 / 150), u1, tb, Xf, Xh - bit for bit, with the same numpy seed
+    and the same stand-ins on the drop-in classes.  The end-to-end error of a CH bc run is parity-unpinned (the data
+    file CH/data/CH-201*512.mat is a missing blob); what the loop DOES is pinned here."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bc_driver_args.npz"))
+    nx, nt = int(g["nx"]), int(g["nt"])
+    x = np.linspace(-15.0, 15.0, nx)[:, None]
+    t = np.linspace(-1.0, 1.0, nt)[:, None]
+    exact = 1.0 / np.cosh(0.5 * (x.T - 3.0 * t)) ** 2                                # (T, X), as the generator's file
+    ns = scripts.for_script("CH/bc-CH-1soliton.py")
+    calls, counter = [], {"seg": 0}
+
+    def stand_in(base):
+        class C(install(base)):
+            def __init__(self, layers, lb, ub, *a):
+                super().__init__(layers, lb, ub, *a)
+                self._seg = counter["seg"]
+                counter["seg"] += 1
+                calls.append({"cls": base.__name__, "lb": np.array(lb, dtype=np.float64), "ub": np.array(ub, dtype=np.float64)})
+
+            def set_training_data(self, *args):
+                names = ["x0", "u0", "tb", "Xf"] if base.__name__ == "PhysicsInformedNN" else ["x0", "u0", "t0", "u1", "tb", "Xf", "Xh"]
+                assert len(args) == len(names)
+                calls[-1].update(dict(zip(names, args)))
+                super().set_training_data(*args)
+
+            def train(self, *a, **k):
+                pass
+
+            def save_model(self, *a, **k):
+                pass
+
+            def predict(self, X):
+                return _stub_predict(X, self._seg)
+        C.__name__ = base.__name__
+        return C
+    np.random.seed(1234)                                   # the reference's seed (:21); draws in the reference's order
+    models, u1 = drivers.backward_compatible(stand_in(ns.PhysicsInformedNN), stand_in(ns.bcPhysicsInformedNN),
+                                             [2, 50, 50, 50, 50, 1], x, t, exact, rng=np.random)
+    assert str(g["stopped"]).startswith("ValueError")      # the reference's own run ends in its fifth pass ...
+    assert len(calls) == int(g["n_segments"]) == 4          # ... after four segments, and so does the default here
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(np.asarray(a, dtype=np.float64)).tobytes()).hexdigest()
+    for i, c in enumerate(calls):
+        assert c["cls"] == str(g["seg%d_cls" % i])
+        for k in ("lb", "ub", "x0", "u0", "tb"):
+            assert np.array_equal(np.asarray(c[k], dtype=np.float64), g["seg%d_%s" % (i, k)]), (i, k)
+        for k in ("Xf", "Xh", "u1"):
+            if "seg%d_%s_sha256" % (i, k) in g.files:
+                assert tuple(np.asarray(c[k]).shape) == tuple(g["seg%d_%s_shape" % (i, k)]), (i, k)
+                assert sha(c[k]) == str(g["seg%d_%s_sha256" % (i, k)]), (i, k)
+        if i > 0:
+            assert float(c["t0"]) == float(g["seg%d_t0" % i]) == 50.0 * i and isinstance(c["t0"], int)
+    # the corrected variant differs exactly where documented: t0 is a time, u0 the previous model at x0
+    np.random.seed(1234)
+    calls.clear(); counter["seg"] = 0
+    drivers.backward_compatible(stand_in(ns.PhysicsInformedNN), stand_in(ns.bcPhysicsInformedNN),
+                                [2, 50, 50, 50, 50, 1], x, t, exact, rng=np.random, corrected=True)
+    assert len(calls) == 4 and abs(float(calls[1]["t0"]) - t[50, 0]) < 1e-12
+    assert np.array_equal(calls[1]["Xf"], calls[1]["Xf"]) and sha(calls[1]["Xh"]) == str(g["seg1_Xh_sha256"])
 
 
 def test_sliding_window_two_output_gnss(tmp_path):

@@ -11,8 +11,8 @@ fp64 result stored in tests/golden:
       reference's OWN fp32 run is 1e-4..3e-3 away from its fp64 run: residual, loss and gradient
       no worse than NOISE_FACTOR = 2 x the reference's own fp32 error, both taken as RMS over
       the 12 batches of 256 points of tests/golden/noise_*.npz
-      (test_fp32_noise_vs_reference; measured 0.7-1.8x).  One documented exception:
-      Camassa-Holm (CH_NOISE_FACTORS).
+      (48 batches for Camassa-Holm; test_fp32_noise_vs_reference; measured 0.7-1.8x, every case listed in
+      DESIGN.md section 2 / profiles/r03_noise_report.txt).  No exceptions.
   The per-case asserts on ONE 192-point batch (test_residual_and_derivatives,
   test_loss_and_gradient) keep 2.5x / 5x sanity margins only: on a single batch the ratio
   between two equally accurate fp32 implementations swings between 0.2x and 8x
@@ -35,15 +35,13 @@ KINDS = [("valu", KERNEL_VALU), ("mfma", KERNEL_MFMA)]
 
 # SURVEY 8(c) P2/P3 in RMS form: error <= max(1e-5, NOISE_FACTOR x the reference's own fp32 error)
 NOISE_FACTOR = 2.0
-# Camassa-Holm at its shipped checkpoint is the one case that cannot meet it: every single derivative is as
-# accurate as the reference's (3.7e-7 .. 2.1e-5, same as its fp32 autograd), but the reference's derivative
-# errors are correlated through its one nested autograd graph and cancel in f = u_t - u_xxt + 3uu_x - 2u_xx u_x
-# - u u_xxx the way the exact terms do (pieces of 7.5e-5, 4.3e-5, 1.8e-5 leave 1.9e-5), while the rounding
-# errors of the jets' per-component dot products do not (2.6e-5, 3.5e-5, 2.1e-5 leave 3.5e-5).  The fp32 C
-# restatement with libm tanh shows the same 2.9x / 3.3x (f / gradient), so this is the fp32 floor of the
-# Taylor-jet formulation for this net, not of its HIP implementation; measured on the GPU: f 3.9-4.2x,
-# loss 3.4-8.4x, gradient 6.0-8.7x (the gradient is J^T f at a minimum, where J^T f nearly vanishes).
-CH_NOISE_FACTORS = {"f": 6.0, "l": 12.0, "g": 12.0}
+# Camassa-Holm at its shipped checkpoint needed an exception in round 2 (6x / 12x / 12x): plain float32 jets are
+# 3.5x / 3.8x / 5x noisier there than the reference (the C restatement shows the same: tests/test_oracle_golden.py,
+# test_ch_precise_top_model).  Round 3 found where that noise is made (the LAST hidden Linear layer's value / x-slope /
+# t-slope components and the output layer: tools/ch_noise_lab.py) and accumulates exactly those dot products in
+# float64 (EqTraits<EQ_CH>::PRECISE, jet_math.hpp): measured 1.0-1.2x (f), 1.2-1.4x (gradient), 1.6-1.8x (loss) on
+# the 48 batches of noise_ch_ckpt.npz - CH now meets the common bar.  (CH's errors are heavy-tailed - a few points
+# at the crest of the peakon carry most of the sum of squares - so its fixture holds 48 batches, not 12.)
 
 
 def rel(a, b):
@@ -443,7 +441,7 @@ NOISE_CASES = sorted(fn[6:-4] for fn in os.listdir(GOLDEN) if fn.startswith("noi
 def test_fp32_noise_vs_reference(name, kname, kernel):
     """SURVEY 8(c) P2/P3 at the reference's shipped checkpoints: residual, loss and flat gradient of the
     HIP path are no further from the fp64 truth than NOISE_FACTOR x the reference's own fp32 run is,
-    RMS over 12 batches of 256 points (fixture: the reference's per-batch fp32 errors, generated by
+    RMS over 12 batches of 256 points (48 for Camassa-Holm; fixture: the reference's per-batch fp32 errors, generated by
     importing its scripts; truth: the fp64 oracle, which must agree with the reference's fp64 to 1e-9)."""
     from noise_stats import noise_stats
     g = np.load(os.path.join(GOLDEN, "noise_" + name + ".npz"))
@@ -454,7 +452,7 @@ def test_fp32_noise_vs_reference(name, kname, kernel):
             pytest.skip(str(ex))
         raise
     assert s["oracle_vs_ref64"] < 1e-9
-    fac = CH_NOISE_FACTORS if name.startswith("ch_") else {"f": NOISE_FACTOR, "l": NOISE_FACTOR, "g": NOISE_FACTOR}
+    fac = {"f": NOISE_FACTOR, "l": NOISE_FACTOR, "g": NOISE_FACTOR}
     assert s["f"] <= max(1e-5, fac["f"] * s["ref_f"]), ("f", s["f"] / s["ref_f"])
     assert s["l"] <= max(1e-5, fac["l"] * s["ref_l"]), ("loss", s["l"] / s["ref_l"])
     assert s["g"] <= max(1e-5, fac["g"] * s["ref_g"]), ("grad", s["g"] / s["ref_g"])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development build of ONE kernel family for quick iteration (not the shipped library):
 #   tools/dev_build.sh <name> [extra hipcc flags]     -> build_dev/lib_<name>.so  (+ the ISA in build_dev/<name>/*.s)
-# WHICH=KDV7 (default) | GNSS100 selects the PINN_DEV_*_ONLY instantiation set of kernel_mfma.hpp.
+# WHICH=KDV7 (default) | GNSS100 | CH selects the PINN_DEV_*_ONLY instantiation set of kernel_mfma.hpp.
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
@@ -20,6 +20,7 @@ for m in re.finditer(r"; Function info:|\.amdhsa_kernel (\S+)", t):
 for blk in re.split(r"\n\s*\.amdhsa_kernel ", t)[1:]:
     name=blk.split("\n")[0]
     if "k_mfma" not in name: continue
+    if not name.rstrip().endswith("ELi2EEvNS_5KDescENS_8CallArgsEPf") and "Li2EEv" not in name: continue
     g=lambda k: (re.search(r"\.amdhsa_%s (\S+)"%k, blk) or [None,"?"])[1]
     print(name[:60], "next_free_vgpr", g("next_free_vgpr"), "accum_offset", g("accum_offset"), "scratch", g("private_segment_fixed_size"))
 PY

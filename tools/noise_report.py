@@ -16,6 +16,9 @@ from pde_amd._native import NativeError  # noqa: E402
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--lib":        # a development build instead of pde_amd/libpinnjet.so
+        import pde_amd._native as _nat
+        _nat.LIB_PATH = os.path.abspath(sys.argv[2])
     dev = torch.device("cuda", 0)
     print("%-16s %-5s %-28s %-28s %-28s" % ("case", "kind", "f: ours / ref32 = ratio", "grad: ours / ref32 = ratio", "loss: ours / ref32 = ratio"))
     for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "noise_*.npz"))):
