@@ -31,8 +31,26 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic flops per point per closure, SURVEY 8(d): A = 3F
-FLOPS_PER_POINT = {"kdv7_3sol": 4.94e5, "kdv5": 3.68e5, "burgers": 1.96e5, "gnss": 9.5e5, "ch": 5.8e5}
+# jet orders (K, KT) per equation
+ORDERS = {"kdv7_3sol": (7, 1), "kdv5": (5, 1), "burgers": (2, 1), "gnss": (3, 1), "ch": (3, 3)}
+
+
+def algorithmic_flops(layers, eq):
+    """Algorithmic flops per point per closure, SURVEY 8(d): minimal Taylor-mode count, FMA = 2, tanh = 1.
+    M = MACs of one plain forward, H = tanh neurons, J = K+1+KT jet components, c(K) = 2K^2 + 5K (order-K tanh
+    recurrence), t-tangent cost tau = 1 (KT = 1) or 2 c(KT-1) + 2; forward F = 2 M J + H (c(K) + 1 + tau);
+    reverse to the weights = 2F; A = 3F.  Gives SURVEY's figures: 7kdv 4.94e5, 5kdv 3.68e5, Burgers 4x50 1.96e5,
+    GNSS-100 9.5e5, CH-64 5.8e5 (and 7.8e4 for the 8x20 Burgers net).  No recomputation, padding or unused
+    derivatives are counted."""
+    K, KT = ORDERS[eq]
+    c = lambda k: 2 * k * k + 5 * k
+    M = sum(layers[i] * layers[i + 1] for i in range(len(layers) - 1))
+    H = sum(layers[1:-1])
+    J = K + 1 + KT
+    tau = 1 if KT == 1 else 2 * c(KT - 1) + 2
+    return 3.0 * (2 * M * J + H * (c(K) + 1 + tau))
+
+
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector == FP32-input MFMA
 
 # `ckpt`: golden fixture holding the weights of the reference's shipped checkpoint for this config (SURVEY 8(d):
@@ -47,8 +65,12 @@ WORKLOADS = {
                  n=2_000_000, family="gnss", name="NLS sw-GNSS-adamW, [2,100x4,2], N_f=2M"),
     "ch": dict(eq="ch", layers=[2, 64, 64, 64, 64, 1], lb=[-15.0, -1.0], ub=[15.0, 1.0],
                n=1_250_000, family="camassa_holm", name="CH PI, [2,64x4,1], N_f=1.25M per GPU (10M over 8)"),
-    "burgers": dict(eq="burgers", layers=[2] + [20] * 8 + [1], lb=[-1.0, 0.0], ub=[1.0, 0.99],
-                    n=10_000, family="burgers", name="Burgers, [2,20x8,1], N_f=10k"),
+    # the script as committed (Burgers/Burgers_equation(PINN).py:209-210: [2,50x4,1], N_f = 10 000)
+    # with its shipped checkpoint; BASELINE.json words the config as a "9x20 tanh MLP": that net is burgers_9x20
+    "burgers": dict(eq="burgers", layers=[2, 50, 50, 50, 50, 1], lb=[-1.0, 0.0], ub=[1.0, 0.99], ckpt="burgers_ckpt",
+                    n=10_000, family="burgers", name="Burgers_equation(PINN).py, [2,50x4,1], N_f=10k"),
+    "burgers_9x20": dict(eq="burgers", layers=[2] + [20] * 8 + [1], lb=[-1.0, 0.0], ub=[1.0, 0.99],
+                         n=10_000, family="burgers", name="Burgers, [2,20x8,1], N_f=10k"),
 }
 
 
@@ -271,14 +293,15 @@ def main():
         ev1.synchronize()
         kt.append(ev0.elapsed_time(ev1) * 1e-3)
     k_avg = float(np.mean(kt))
-    flops = FLOPS_PER_POINT[w["eq"]] * n_local
+    flops_pp = algorithmic_flops(w["layers"], w["eq"])
+    flops = flops_pp * n_local
     achieved = flops / k_avg / 1e12
     # HBM bytes per launch of that kernel: from the committed rocprofv3 PMC passes (profiles/traffic.json,
     # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE), when this exact workload / size / kernel was profiled
     traffic = None
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as fh:
-            ent = json.load(fh).get("%s|%d|%s" % (w["eq"], n_local, {1: "valu", 2: "mfma"}[eng.kernel_kind]))
+            ent = json.load(fh).get("%s|%d|%s" % (args.workload, n_local, {1: "valu", 2: "mfma"}[eng.kernel_kind]))
         traffic = ent["bytes"] if ent else None
     except (OSError, ValueError, KeyError):
         traffic = None
@@ -334,7 +357,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
                          "kernel_ms": 1e3 * k_avg,
-                         "algorithmic_flops_per_point": FLOPS_PER_POINT[w["eq"]],
+                         "algorithmic_flops_per_point": flops_pp,
                          "note": "FP32 compute roofline (vector == f32-input MFMA peak); "
                                  "algorithmic HBM traffic is 8 B/point (x, t in); `traffic` = HBM bytes per launch "
                                  "looked up in profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "

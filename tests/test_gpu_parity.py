@@ -9,10 +9,10 @@ fp64 result stored in tests/golden:
   P3  loss / flat gradient at xavier weights (no cancellation): <= 1e-5
   P2/P3 at the reference's trained checkpoints, where f is a ~1000x cancellation and the
       reference's OWN fp32 run is 1e-4..3e-3 away from its fp64 run: residual, loss and gradient
-      no worse than NOISE_FACTOR = 2 x the reference's own fp32 error, both taken as RMS over
+      no worse than NOISE_FACTOR = 1.5 x the reference's own fp32 error (SURVEY's factor), both taken as RMS over
       the 12 batches of 256 points of tests/golden/noise_*.npz
       (48 batches for Camassa-Holm; test_fp32_noise_vs_reference; measured 0.7-1.8x, every case listed in
-      DESIGN.md section 2 / profiles/r03_noise_report.txt).  No exceptions.
+      DESIGN.md section 2 / profiles/r03_noise_report.txt).  One looser bar: the Camassa-Holm LOSS, 2x.
   The per-case asserts on ONE 192-point batch (test_residual_and_derivatives,
   test_loss_and_gradient) keep 2.5x / 5x sanity margins only: on a single batch the ratio
   between two equally accurate fp32 implementations swings between 0.2x and 8x
@@ -33,14 +33,21 @@ pytestmark = pytest.mark.gpu
 
 KINDS = [("valu", KERNEL_VALU), ("mfma", KERNEL_MFMA)]
 
-# SURVEY 8(c) P2/P3 in RMS form: error <= max(1e-5, NOISE_FACTOR x the reference's own fp32 error)
-NOISE_FACTOR = 2.0
+# SURVEY 8(c) P2/P3 in RMS form: error <= max(1e-5, NOISE_FACTOR x the reference's own fp32 error).  1.5 is the
+# survey's own factor (round 2 needed 2.0, and 6 / 12 / 12 for Camassa-Holm); measured with the precise top
+# (profiles/r03_noise_report.txt): f 0.49-1.19x, gradient 0.35-1.38x, loss 0.47-1.24x on both kernel families.
+NOISE_FACTOR = 1.5
+# The one looser bar: the LOSS at the Camassa-Holm checkpoint, 1.64x (mfma) / 1.75x (valu).  loss = sum f^2 weights
+# the residual's error by the residual itself, and at this checkpoint both are concentrated in the same handful of
+# points at the crest of the peakon (one point of a 256-point batch can hold 85 % of sum f^2): the statistic has
+# far fewer effective samples than 48 x 256, and the residual (1.0-1.2x) and gradient (1.2-1.4x) bars hold.
+CH_LOSS_FACTOR = 2.0
 # Camassa-Holm at its shipped checkpoint needed an exception in round 2 (6x / 12x / 12x): plain float32 jets are
 # 3.5x / 3.8x / 5x noisier there than the reference (the C restatement shows the same: tests/test_oracle_golden.py,
 # test_ch_precise_top_model).  Round 3 found where that noise is made (the LAST hidden Linear layer's value / x-slope /
 # t-slope components and the output layer: tools/ch_noise_lab.py) and accumulates exactly those dot products in
-# float64 (EqTraits<EQ_CH>::PRECISE, jet_math.hpp): measured 1.0-1.2x (f), 1.2-1.4x (gradient), 1.6-1.8x (loss) on
-# the 48 batches of noise_ch_ckpt.npz - CH now meets the common bar.  (CH's errors are heavy-tailed - a few points
+# float64 (EqTraits<EQ>::PRECISE, jet_math.hpp, on for every residual): measured 1.0-1.2x (f), 1.2-1.4x (gradient),
+# 1.6-1.8x (loss) on the 48 batches of noise_ch_ckpt.npz.  (CH's errors are heavy-tailed - a few points
 # at the crest of the peakon carry most of the sum of squares - so its fixture holds 48 batches, not 12.)
 
 
@@ -452,7 +459,7 @@ def test_fp32_noise_vs_reference(name, kname, kernel):
             pytest.skip(str(ex))
         raise
     assert s["oracle_vs_ref64"] < 1e-9
-    fac = {"f": NOISE_FACTOR, "l": NOISE_FACTOR, "g": NOISE_FACTOR}
+    fac = {"f": NOISE_FACTOR, "l": CH_LOSS_FACTOR if name.startswith("ch_") else NOISE_FACTOR, "g": NOISE_FACTOR}
     assert s["f"] <= max(1e-5, fac["f"] * s["ref_f"]), ("f", s["f"] / s["ref_f"])
     assert s["l"] <= max(1e-5, fac["l"] * s["ref_l"]), ("loss", s["l"] / s["ref_l"])
     assert s["g"] <= max(1e-5, fac["g"] * s["ref_g"]), ("grad", s["g"] / s["ref_g"])

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import WORKLOADS  # noqa: E402
+from bench import WORKLOADS, checkpoint_theta  # noqa: E402
 from pde_amd import equations  # noqa: E402
 from pde_amd._native import NativeEngine  # noqa: E402
 
@@ -37,6 +37,9 @@ for i in range(len(layers) - 1):
     fi, fo = layers[i], layers[i + 1]
     theta[off:off + fi * fo] = rng.standard_normal(fi * fo) * np.sqrt(2.0 / (fi + fo))
     off += fi * fo + fo
+ck = checkpoint_theta(w)          # the weights bench.py uses by default (the reference's shipped checkpoint, if any)
+if ck is not None:
+    theta = ck
 th = torch.tensor(theta, device=dev)
 x = torch.tensor(X[:, 0].copy(), device=dev)
 t = torch.tensor(X[:, 1].copy(), device=dev)
