@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pde_amd import scripts  # noqa: E402
 
 CASES = {
-    "burgers": dict(family="burgers", layers=[2] + [20] * 8 + [1], lb=[-1.0, 0.0], ub=[1.0, 0.99]),
+    "burgers": dict(family="burgers", layers=[2, 50, 50, 50, 50, 1], lb=[-1.0, 0.0], ub=[1.0, 0.99]),
+    "burgers_9x20": dict(family="burgers", layers=[2] + [20] * 8 + [1], lb=[-1.0, 0.0], ub=[1.0, 0.99]),
     "kdv5": dict(family="kdv5_1soliton", layers=[2, 50, 50, 50, 50, 1], lb=[-10.0, -2.0], ub=[10.0, 2.0]),
     "kdv7": dict(family="kdv7_3soliton", layers=[2, 50, 50, 50, 50, 1], lb=[-15.0, -0.5], ub=[15.0, 0.5]),
     "gnss": dict(family="gnss", layers=[2, 100, 100, 100, 100, 2], lb=[-5.0, -2.0], ub=[5.0, 0.0]),
@@ -40,7 +41,7 @@ def run(case, impl, n, iters, graph=False):
     Xf = lb + (ub - lb) * rng.random((n, 2))
     if case == "gnss":
         m.set_training_data(x0, u0, 0.1 * u0, tb, Xf)
-    elif case == "burgers":
+    elif case.startswith("burgers"):
         m.set_training_data(x0, -np.sin(np.pi * x0), tb, Xf, 0.01 / np.pi)
     else:
         m.set_training_data(x0, u0, tb, Xf)
@@ -65,7 +66,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--n", type=int, default=20000)
-    ap.add_argument("--cases", default="burgers,kdv5,kdv7,gnss")
+    ap.add_argument("--cases", default="burgers,burgers_9x20,kdv5,kdv7,gnss")
     ap.add_argument("--only", default="", help="run just this variant: torch | device | device+graph (profiling)")
     a = ap.parse_args()
     for case in a.cases.split(","):
