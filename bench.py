@@ -270,12 +270,13 @@ def main():
     if world > 1:
         eng0 = model.engine_f
         msg = torch.zeros(eng0.P + model._T_SIZE, device=dev)     # the closure's packed buffer
+        from pde_amd.nn import all_reduce_sum       # RCCL: the device buffer goes straight in; gloo rehearsal: staged through the host
         for _ in range(5):
-            dist.all_reduce(msg)
+            all_reduce_sum(msg, group)
         sync()
         t_ar = time.perf_counter()
         for _ in range(50):
-            dist.all_reduce(msg)
+            all_reduce_sum(msg, group)
         torch.cuda.synchronize()
         allreduce_us = 1e6 * (time.perf_counter() - t_ar) / 50
 

@@ -84,6 +84,7 @@ class PhysicsInformedNN:
     hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
     adam_impl = "fused"              # "fused": pde_amd.optim.FusedAdam (one launch per step); "torch": torch.optim.Adam/AdamW
     lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (one launch per direction); "torch": torch.optim.LBFGS
+    shard_loss1_min_rows = 4096      # sharded runs: a bc class's loss1 grid of at least this many rows is sharded over the ranks
     lbfgs_kernels_factory = None     # test hook: callable(n, history) -> stand-in for the L-BFGS launches
     engine_factory = None            # test hook: callable(equation|None, layers, lb, ub, device) -> engine
 
@@ -458,10 +459,28 @@ class PhysicsInformedNN:
             has1 = v.style == "bc" and self.u1 is not None
             hasp = v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0
             hass = bool(getattr(self, "earliest_solutions", ()))
+            one = getattr(self, "_one", None)
+            if one is None or one.device != theta.device:
+                one = self._one = torch.ones((), dtype=torch.float32, device=theta.device)
+            # loss1 of the bc classes runs over the whole history grid (77 312 points in CH/bc-CH-1soliton.py): large
+            # enough to shard like the collocation points (each rank its contiguous rows, value and cotangent scaled
+            # by rows_local / rows) instead of leaving seven ranks waiting for rank 0
+            shard1 = data_terms and has1 and self._X1.shape[0] >= self.shard_loss1_min_rows
+            if shard1:
+                R, r = dist.get_world_size(self.group), dist.get_rank(self.group)
+                n1 = self._X1.shape[0]
+                q1, rem1 = divmod(n1, R)
+                lo1 = r * q1 + min(r, rem1)
+                hi1 = lo1 + q1 + (1 if r < rem1 else 0)
+                if hi1 > lo1:
+                    frac = torch.full((), (hi1 - lo1) / float(n1), dtype=torch.float32, device=theta.device)
+                    X1s, t1s = self._X1[lo1:hi1], self._tgt1[lo1:hi1]
+                    o = eng.forward(theta, X1s, None)
+                    slot = tail[T._T_L1:T._T_L1 + 2]
+                    data_loss_values(o, t1s, o.shape[0], 0, False, out_losses=slot)
+                    slot.mul_(frac)
+                    eng.forward_vjp(theta, X1s, None, data_loss_cot(o, t1s, o.shape[0], 0, False, frac, frac), g)
             if data_terms and dist.get_rank(self.group) == 0:
-                one = getattr(self, "_one", None)
-                if one is None or one.device != theta.device:
-                    one = self._one = torch.ones((), dtype=torch.float32, device=theta.device)
                 n0, nb = self.x0.shape[0], self.x_lb.shape[0]
                 dirichlet = v.bc == "dirichlet"
                 out = eng.forward(theta, self._X_data, None)
@@ -473,7 +492,7 @@ class PhysicsInformedNN:
                     data_loss_values(o, tgt, o.shape[0], 0, False, out_losses=tail[slot:slot + 2])
                     eng.forward_vjp(theta, X, None, data_loss_cot(o, tgt, o.shape[0], 0, False, one, one), g)
 
-                if has1:
+                if has1 and not shard1:
                     mse_term(self._X1, self._tgt1, T._T_L1)
                 if hasp:
                     mse_term(self.X_prev, self._tgt_prev, T._T_LPREV)
@@ -560,16 +579,22 @@ class PhysicsInformedNN:
     def check_replicas(self):
         """Sharded runs keep the weights identical on every rank WITHOUT a broadcast: every rank applies
         the same optimizer update to the same all-reduced closure result (_loss_terms_sharded).  This verifies it:
-        the element-wise MIN and MAX over ranks of [sum theta, sum theta^2] must coincide.  Called with
-        the every-100-iterations log line; raises on every rank if the replicas have drifted apart."""
+        the element-wise MIN and MAX over ranks of [sum theta, sum theta^2] must coincide (ONE all-reduce:
+        MAX of [sig, -sig]).  Called with the every-100-iterations log line; raises on every rank if the replicas
+        have drifted apart."""
         if self.group is None:
             return
         import torch.distributed as dist
         th = self.dnn.flat_theta().detach().double()
         sig = torch.stack([th.sum(), (th * th).sum()])
-        lo, hi = sig.clone(), sig.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        both = torch.cat([sig, -sig])
+        if both.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = both.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            both = host
+        else:
+            dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)
+        hi, lo = both[:2], -both[2:]
         if not torch.equal(lo, hi):
             raise RuntimeError("weights differ across ranks (checksums min %s max %s): the replicas no longer "
                                "follow the same trajectory" % (lo.tolist(), hi.tolist()))

@@ -24,7 +24,9 @@ def _free_port():
 
 # golden case -> (drop-in class, feed kind): a one-output PI class, and a two-output class with the
 # list-of-terms loss_s (NLS/IBCtest.py:252-258) that only rank 0 evaluates
-CASES = {"kdv5_xavier": ("5kdv/PI-51.py", "pi"), "nls_ibc_xavier": ("NLS/sw-PINN-rogue.py", "gnss_es")}
+CASES = {"kdv5_xavier": ("5kdv/PI-51.py", "pi"), "nls_ibc_xavier": ("NLS/sw-PINN-rogue.py", "gnss_es"),
+         # a bc class: its loss1 history grid is sharded over the ranks like the collocation points
+         "kdv7_bc_xavier": ("7kdv/bc-7kdv3soliton.py", "bc")}
 
 
 def _worker(rank, world, port, name, out):
@@ -37,7 +39,9 @@ def _worker(rank, world, port, name, out):
     from test_host_logic import feed, flat_grad, load_theta
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     script, kind = CASES[name]
-    cls = install(scripts.for_script(script).PhysicsInformedNN)
+    ns = scripts.for_script(script)
+    cls = install(ns.bcPhysicsInformedNN if kind == "bc" else ns.PhysicsInformedNN)
+    cls.shard_loss1_min_rows = 8
     m = cls(g["layers"].tolist(), g["lb"], g["ub"], process_group=dist.group.WORLD)
     load_theta(m, g["theta"])
     feed(m, g, kind)
