@@ -171,15 +171,33 @@ int pinn_loss_grad(pinn_handle *h, const float *theta, const float *x, const flo
  *            the previous call/step), pair stored if y.s > 1e-10 (oldest dropped when full),
  *            H = y.s/y.y, d = two-loop recursion applied to -g.  Always: g_prev = g and
  *            stats8 = [g.d, sum|g|, max|d|, max|g|, pairs held, H_diag, pair accepted (0/1), 0].
- *            Four launches (row dot products over the whole chip, the scalar recursion, the
- *            combination, the statistics); deterministic (fixed-order reductions, no atomics).
+ *            Three launches (row dot products over the whole chip, the scalar recursion in one
+ *            workgroup, the combination, whose last workgroup folds the statistics); deterministic
+ *            (fixed-order reductions; the one atomic is a ticket).
+ * pinn_lbfgs_direction_advance: the same, and when x != NULL the combination launch also moves the
+ *            weights to the line search's first trial point: x0 = x, x = x + t_next * d (x, x0: n floats;
+ *            torch.optim.LBFGS does this as a clone and an add per evaluation, torch/optim/lbfgs.py
+ *            _directional_evaluate).
  * pinn_lbfgs_eval_stats: out4 = [*loss (0 when NULL), g.d, max|g|, sum|g|] after one closure
- *            evaluation of the line search. */
+ *            evaluation of the line search.
+ * pinn_lbfgs_eval_stats_keep: the same, and g_copy (n floats, may be NULL) = g: the gradient the line
+ *            search keeps for the point (torch: flat_grad.clone()).  host13 (may be NULL): 13 words of
+ *            pinned host memory, as a device pointer (pinn_host_device_pointer), that receive
+ *            [stats8 (8 floats, skipped when stats8 is NULL) | out4 | ticket (int32)], the ticket last and
+ *            after a system-scope fence: the host polls that word instead of waiting on the stream
+ *            (torch.optim.LBFGS blocks on `float(loss)` and on every scalar it compares).
+ * pinn_host_device_pointer: the device address of pinned (hipHostMalloc / torch pin_memory) host memory;
+ *            PINN_ERR_HIP when the memory is not mapped into the device's address space. */
 int64_t pinn_lbfgs_workspace_floats(int64_t n, int32_t history);
 int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const float *g, float *d, float t,
                          int32_t first, float *stats8, void *stream);
+int pinn_lbfgs_direction_advance(float *workspace, int64_t n, int32_t history, const float *g, float *d, float t,
+                                 int32_t first, float *stats8, float *x, float *x0, float t_next, void *stream);
 int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float *loss, float *out4,
                           void *stream);
+int pinn_lbfgs_eval_stats_keep(const float *g, const float *d, int64_t n, const float *loss, float *out4,
+                               float *g_copy, const float *stats8, float *host13, int32_t ticket, void *stream);
+int pinn_host_device_pointer(void *host, void **device);
 
 /* ---- data terms of backward() on the outputs of one net_u batch ------------------------------------------
  * loss0 / loss_b of the reference's backward() (7kdv/PI-7kdv3soliton.py:99-105; two outputs:
@@ -196,6 +214,17 @@ int pinn_data_loss(const float *out, const float *tgt0, int32_t n0, int32_t nb, 
                    float *losses, void *stream);
 int pinn_data_loss_cotangent(const float *out, const float *tgt0, int32_t n0, int32_t nb, int32_t nout, int32_t dirichlet,
                              const float *g0, const float *gb, float *gbar, void *stream);
+
+/* ---- the tail of backward(): `loss = loss0 + loss_b [+ loss1] [+ loss_prev] [+ loss_s] + loss_f; loss.backward()`
+ * (7kdv/PI-7kdv3soliton.py:110-111; bc: 7kdv/bc-7kdv3soliton.py:252-253; sw: 7kdv/sw-73.py:142-143) once every
+ * term's value and flat weight gradient exist, in ONE launch instead of a divide and four adds:
+ *   loss2[1] = loss_f = (sums[0] + ... + sums[nf-1]) / n_total        (sums: what pinn_loss_grad accumulated)
+ *   loss2[0] = loss   = (((terms[0] + terms[1]) + loss_f) + terms[2]) + ...   (float32, in the reference's order:
+ *                       terms = loss0, loss_b, then loss1 / loss_prev / loss_s as present)
+ *   grad[i]  = ga[i] + gb[i]   (accumulate != 0: grad[i] += ga[i] + gb[i]; gb may be NULL), i < P
+ * n_terms <= 16, nf <= 3. */
+int pinn_closure_sum(const float *terms, int32_t n_terms, const float *sums, int32_t nf, float n_total, float *loss2,
+                     const float *ga, const float *gb, float *grad, int64_t P, int32_t accumulate, void *stream);
 
 /* ---- Adam / AdamW on the device, one launch per step ------------------------------------
  * Replaces torch.optim.Adam / AdamW(weight_decay=1e-2).step() of the reference's Adam phase

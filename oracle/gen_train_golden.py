@@ -7,7 +7,8 @@ own `train(nIter, None, 0, LBFGS_max_iter)` — torch.optim.Adam/AdamW for nIter
 float32 (its arithmetic) and once in float64 (truth).  Stored: the data, the initial weights, the weights after the
 Adam phase alone and after Adam + L-BFGS in both precisions, the closure counts and the final losses — and the float32
 run repeated with the collocation points in another order (the same loss, other rounding): the strong-Wolfe line search
-amplifies rounding (Camassa-Holm: 4e-6 -> 1e-4 of the distance travelled), and that run measures by how much.
+amplifies rounding (Camassa-Holm: 4e-6 -> 1e-4 of the distance travelled), and that run measures by how much; a third
+float32 run starts from weights moved by about one rounding (relative 1e-7).
 
 tests/test_gpu_train_golden.py holds the drop-in classes on the HIP path to it: after the Adam phase the weights must be as
 close to the float64 trajectory as the reference's own float32 run is (factor 3, floor 1e-6); after the L-BFGS phase
@@ -102,6 +103,19 @@ def main():
                 model4.train(N_ADAM, None, 0, N_LBFGS)
                 out["theta_end32p"] = flat_theta(model4).astype(np.float64)
                 out["iter_end32p"] = np.array(model4.iter)
+                # ... and with the initial weights moved by about one float32 rounding (relative 1e-7 * N(0,1))
+                torch.manual_seed(4321)
+                model5 = mod.PhysicsInformedNN(layers, lb, ub)
+                if two:
+                    model5.set_training_data(x0, u0, v0, tb, Xf)
+                else:
+                    model5.set_training_data(x0, u0, tb, Xf)
+                with torch.no_grad():
+                    for prm in model5.dnn.parameters():
+                        prm.mul_(1.0 + 1e-7 * torch.randn_like(prm))
+                model5.train(N_ADAM, None, 0, N_LBFGS)
+                out["theta_end32q"] = flat_theta(model5).astype(np.float64)
+                out["iter_end32q"] = np.array(model5.iter)
             torch.manual_seed(4321)
             model3 = mod.PhysicsInformedNN(layers, lb, ub)
             if two:
@@ -121,9 +135,11 @@ def main():
             rec["%s_%s" % (name, k)] = v
         ea = np.linalg.norm(out["theta_adam32"] - out["theta_adam64"]) / np.linalg.norm(out["theta_adam64"] - theta0)
         tr = np.linalg.norm(out["theta_end64"] - theta0)
-        print("%-14s end: f32 %.2e, f32 with permuted points %.2e of the distance travelled (closures %d)" % (
-            name, np.linalg.norm(out["theta_end32"] - out["theta_end64"]) / tr,
-            np.linalg.norm(out["theta_end32p"] - out["theta_end64"]) / tr, int(out["iter_end32p"])))
+        print("%-14s end: f32 %.2e, f32 with permuted points %.2e, f32 with weights moved by 1e-7 %.2e of the distance travelled "
+              "(closures %d, %d)" % (
+                  name, np.linalg.norm(out["theta_end32"] - out["theta_end64"]) / tr,
+                  np.linalg.norm(out["theta_end32p"] - out["theta_end64"]) / tr,
+                  np.linalg.norm(out["theta_end32q"] - out["theta_end64"]) / tr, int(out["iter_end32p"]), int(out["iter_end32q"])))
         print("%-14s Adam phase: |theta32 - theta64| / |theta64 - theta0| = %.2e; closures %d / %d / %d; loss %.4e -> %.4e (f32) %.4e (f64)"
               % (name, ea, int(out["iter_adam"]), int(out["iter_end32"]), int(out["iter_end64"]), float(out["loss_start64"]),
                  float(out["loss_end32"]), float(out["loss_end64"])))

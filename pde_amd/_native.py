@@ -38,8 +38,9 @@ SYMBOLS = [
     "pinn_create", "pinn_destroy", "pinn_param_count", "pinn_jet_count", "pinn_nf", "pinn_nout",
     "pinn_kernel_kind", "pinn_forward", "pinn_forward_vjp", "pinn_residual_fwd", "pinn_residual_vjp",
     "pinn_loss_grad", "pinn_error_string", "pinn_reserve", "pinn_forward_vjp_static", "pinn_residual_from_derivs", "pinn_adam_step",
-    "pinn_data_loss", "pinn_data_loss_cotangent",
+    "pinn_data_loss", "pinn_data_loss_cotangent", "pinn_closure_sum",
     "pinn_lbfgs_workspace_floats", "pinn_lbfgs_direction", "pinn_lbfgs_eval_stats",
+    "pinn_lbfgs_direction_advance", "pinn_lbfgs_eval_stats_keep", "pinn_host_device_pointer",
 ]
 
 
@@ -70,10 +71,14 @@ def load_library():
     lib.pinn_lbfgs_workspace_floats.restype = i64
     lib.pinn_lbfgs_direction.argtypes = [vp, i64, ctypes.c_int32, vp, vp, f32, ctypes.c_int32, vp, vp]
     lib.pinn_lbfgs_eval_stats.argtypes = [vp, vp, i64, vp, vp, vp]
+    lib.pinn_lbfgs_direction_advance.argtypes = [vp, i64, ctypes.c_int32, vp, vp, f32, ctypes.c_int32, vp, vp, vp, f32, vp]
+    lib.pinn_lbfgs_eval_stats_keep.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, ctypes.c_int32, vp]
+    lib.pinn_host_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, ctypes.c_double, ctypes.c_double, f32, f32, ctypes.c_int32, vp]
     i32 = ctypes.c_int32
     lib.pinn_data_loss.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.pinn_data_loss_cotangent.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.pinn_closure_sum.argtypes = [vp, i32, vp, i32, f32, vp, vp, vp, vp, i64, i32, vp]
     lib.pinn_error_string.argtypes = [ctypes.c_int]
     lib.pinn_error_string.restype = ctypes.c_char_p
     _lib = lib
@@ -133,6 +138,22 @@ def data_loss_cotangent(out, tgt0, n0, nb, dirichlet, g0, gb):
                                                        g0.data_ptr(), gb.data_ptr(), gbar.data_ptr(), _cur_stream(out)),
                "pinn_data_loss_cotangent")
     return gbar
+
+
+def closure_sum(terms, n_terms, sums, n_total, ga, gb, grad, accumulate):
+    """The tail of backward() in one launch (include/pinnjet.h, pinn_closure_sum): returns loss2 = [loss, loss_f] with
+    loss_f = sum(sums) / n_total and loss = terms[0] + terms[1] + loss_f + terms[2] + ..., and writes (or adds, when
+    `accumulate`) ga + gb into the flat gradient `grad`."""
+    P = grad.numel()
+    for v in (terms, sums, ga, gb, grad):
+        assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.device == grad.device
+    assert ga.numel() == P and gb.numel() == P and terms.numel() >= n_terms and 0 <= sums.numel() <= 3
+    loss2 = torch.empty(2, dtype=torch.float32, device=grad.device)
+    with torch.cuda.device(grad.device):
+        _check(load_library().pinn_closure_sum(terms.data_ptr(), int(n_terms), sums.data_ptr(), sums.numel(), float(n_total),
+                                               loss2.data_ptr(), ga.data_ptr(), gb.data_ptr(), grad.data_ptr(), P,
+                                               1 if accumulate else 0, _cur_stream(grad)), "pinn_closure_sum")
+    return loss2
 
 
 class NativeEngine:
@@ -272,8 +293,19 @@ class NativeLBFGSKernels:
         if floats <= 0:
             raise NativeError("pinn_lbfgs_workspace_floats(%d, %d) failed (%d)" % (n, history, floats))
         self.ws = torch.zeros(floats, dtype=torch.float32, device=self.device)
-        self.stats = torch.zeros(8, dtype=torch.float32, device=self.device)
-        self.out = torch.zeros(4, dtype=torch.float32, device=self.device)
+        # what the host reads per iteration, side by side: ONE device->host copy fetches both
+        self.both = torch.zeros(12, dtype=torch.float32, device=self.device)
+        self.stats, self.out = self.both[:8], self.both[8:]
+        # ... and their mirror in pinned host memory, which the statistics launch writes itself (ticket last): the
+        # host polls the ticket instead of enqueuing a copy and sleeping on the stream
+        self.mirror = torch.zeros(16, dtype=torch.float32, pin_memory=True)
+        dptr = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.pinn_host_device_pointer(self.mirror.data_ptr(), ctypes.byref(dptr))
+        self.mirror_dev = dptr.value if rc == 0 else None
+        self._mirror_f = self.mirror.numpy()
+        self._mirror_i = self._mirror_f.view("int32")
+        self.ticket = 0
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -281,18 +313,46 @@ class NativeLBFGSKernels:
     def _chk(self, v):
         assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == self.n and v.device == self.device
 
-    def direction(self, g, d, t, first):
+    def direction(self, g, d, t, first, x=None, x0=None, t_next=0.0):
+        """stats8 of the new direction; with `x`: also x0 = x and x += t_next * d (the line search's first trial point)"""
         self._chk(g); self._chk(d)
+        if x is not None:
+            self._chk(x); self._chk(x0)
         with torch.cuda.device(self.device):
-            _check(self.lib.pinn_lbfgs_direction(self.ws.data_ptr(), self.n, self.history, g.data_ptr(), d.data_ptr(),
-                                                 float(t), 1 if first else 0, self.stats.data_ptr(), self._stream()),
-                   "pinn_lbfgs_direction")
+            _check(self.lib.pinn_lbfgs_direction_advance(self.ws.data_ptr(), self.n, self.history, g.data_ptr(), d.data_ptr(),
+                                                         float(t), 1 if first else 0, self.stats.data_ptr(),
+                                                         x.data_ptr() if x is not None else None,
+                                                         x0.data_ptr() if x is not None else None, float(t_next),
+                                                         self._stream()), "pinn_lbfgs_direction_advance")
         return self.stats
 
-    def eval_stats(self, g, d, loss):
+    def eval_stats(self, g, d, loss, g_copy=None):
+        """out4 of one line-search evaluation; with `g_copy`: also g_copy = g (the gradient the search keeps for the
+        point).  The launch also mirrors [stats8 | out4] into pinned host memory: `fetch()` returns them."""
         self._chk(g); self._chk(d)
+        if g_copy is not None:
+            self._chk(g_copy)
         loss = loss.detach().reshape(-1).float()
+        assert loss.device == self.device
+        self.ticket = (self.ticket + 1) & 0x3fffffff
         with torch.cuda.device(self.device):
-            _check(self.lib.pinn_lbfgs_eval_stats(g.data_ptr(), d.data_ptr(), self.n, loss.data_ptr(),
-                                                  self.out.data_ptr(), self._stream()), "pinn_lbfgs_eval_stats")
+            _check(self.lib.pinn_lbfgs_eval_stats_keep(g.data_ptr(), d.data_ptr(), self.n, loss.data_ptr(), self.out.data_ptr(),
+                                                       g_copy.data_ptr() if g_copy is not None else None,
+                                                       self.stats.data_ptr(), self.mirror_dev, self.ticket, self._stream()),
+                   "pinn_lbfgs_eval_stats_keep")
         return self.out
+
+    def fetch(self):
+        """(stats8, out4) of the last eval_stats call as Python floats, or None when the host mirror is not available.
+        Polls the ticket word the launch writes last; falls back to a stream wait if it takes seconds."""
+        if self.mirror_dev is None:
+            return None
+        mi, tk, spins = self._mirror_i, self.ticket, 0
+        while mi[12] != tk:
+            spins += 1
+            if spins > 4000000:
+                torch.cuda.current_stream(self.device).synchronize()
+                if mi[12] != tk:
+                    raise NativeError("the statistics of a line-search evaluation never reached the host")
+        v = self._mirror_f[:12].tolist()
+        return v[:8], v[8:]

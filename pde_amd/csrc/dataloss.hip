@@ -13,6 +13,7 @@
 // which pinn_forward_vjp turns into the weight gradient.  Sums in float64, one workgroup, fixed order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/pinnjet.h"
 
@@ -77,9 +78,53 @@ __global__ __launch_bounds__(256) void k_data_cotangent(const float *__restrict_
     }
 }
 
+// The tail of backward(): `loss = loss0 + loss_b [+ loss1] [+ loss_prev] [+ loss_s] + loss_f; loss.backward()`
+// (7kdv/PI-7kdv3soliton.py:110-111, 7kdv/bc-7kdv3soliton.py:252-253, 7kdv/sw-73.py:142-143) once every term's value and weight gradient exist: the float32 sums in the
+// order the reference adds them, and the two flat gradients (data terms, collocation term) added into `.grad`.
+__global__ __launch_bounds__(256) void k_closure_sum(const float *__restrict__ terms, int n_terms, const float *__restrict__ sums,
+                                                      int nf, float n_total, float *__restrict__ loss2,
+                                                      const float *__restrict__ ga, const float *__restrict__ gb,
+                                                      float *__restrict__ grad, long long P, int accumulate)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < P) {
+        float v = ga[i];
+        if (gb) v += gb[i];
+        grad[i] = accumulate ? grad[i] + v : v;
+    }
+    if (i == 0) {
+        float lf = 0.0f;
+        if (nf > 0) {
+            lf = sums[0];
+            for (int c = 1; c < nf; ++c) lf += sums[c];
+            lf = lf / n_total;
+        }
+        // the reference's order: loss0 + loss_b + loss_f + (loss1 | loss_prev | loss_s)
+        float l = n_terms > 0 ? terms[0] : 0.0f;
+        if (n_terms > 1) l += terms[1];
+        l += lf;
+        for (int k = 2; k < n_terms; ++k) l += terms[k];
+        loss2[0] = l;
+        loss2[1] = lf;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int pinn_closure_sum(const float *terms, int32_t n_terms, const float *sums, int32_t nf, float n_total, float *loss2,
+                     const float *ga, const float *gb, float *grad, int64_t P, int32_t accumulate, void *stream)
+{
+    if (!loss2 || !ga || !grad || (n_terms > 0 && !terms) || (nf > 0 && !sums)) return PINN_ERR_NULL;
+    if (n_terms < 0 || n_terms > 16 || nf < 0 || nf > 3 || P <= 0 || !(n_total > 0.0f)) return PINN_ERR_INVALID_DESC;
+    if (P > (1LL << 30)) return PINN_ERR_TOO_LARGE;
+    hipLaunchKernelGGL(k_closure_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, terms, n_terms, sums,
+                       nf, n_total, loss2, ga, gb, grad, (long long)P, accumulate);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "pinn_closure_sum: %s\n", hipGetErrorString(e));
+    return e == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+}
 
 int pinn_data_loss(const float *out, const float *tgt0, int32_t n0, int32_t nb, int32_t nout, int32_t dirichlet,
                    float *losses, void *stream)

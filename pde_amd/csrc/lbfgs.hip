@@ -38,8 +38,9 @@ constexpr int LB_NDOT = 5;
 
 // workspace header (ints), then float64 scalars, then float vectors; offsets in BYTES
 struct LbLayout {
-    int64_t hdr;        // int[8]: count, free slot, accept flag
+    int64_t hdr;        // int[8]: count, free slot, accept flag, ticket of k_combine's last-block fold
     int64_t ord;        // int[hist+1]: physical slot of logical pair k (oldest first)
+    int64_t live;       // int[hist+1]: physical slot holds a stored pair
     int64_t H;          // double[2]: H_diag
     int64_t ro;         // double[hist+1] by physical slot
     int64_t b, c;       // double[hist+1]: s_j.g, y_j.g by physical slot
@@ -58,10 +59,11 @@ inline __host__ __device__ LbLayout lb_layout(int64_t n, int hist) {
     L.slots = hist + 1;
     L.np = (int)((n + 63) & ~int64_t(63));
     L.nchunk = (int)((n + LB_CHUNK - 1) / LB_CHUNK);
-    L.ncomb = (int)((n + LB_BLOCK - 1) / LB_BLOCK);
+    L.ncomb = (int)((n + 63) / 64);
     int64_t o = 0;
     L.hdr = o; o = al256(o + 8 * 4);
     L.ord = o; o = al256(o + int64_t(L.slots) * 4);
+    L.live = o; o = al256(o + int64_t(L.slots) * 4);
     L.H = o; o = al256(o + 16);
     L.ro = o; o = al256(o + int64_t(L.slots) * 8);
     L.b = o; o = al256(o + int64_t(L.slots) * 8);
@@ -123,12 +125,9 @@ __global__ __launch_bounds__(LB_BLOCK) void k_dots(char *__restrict__ ws, int n,
     __shared__ double red[(LB_BLOCK / 64) * LB_NDOT];
     const LbLayout L = lb_layout(n, hist);
     const int *hdr = at<int>(ws, L.hdr);
-    const int *ord = at<int>(ws, L.ord);
-    const int count = hdr[0], cand = hdr[1];
+    const int cand = hdr[1];
     const int slot = blockIdx.y, chunk = blockIdx.x;
-    bool live = slot == cand;
-    for (int k = 0; k < count && !live; ++k) live = ord[k] == slot;
-    if (!live) return;                                   // uniform over the workgroup
+    if (slot != cand && at<int>(ws, L.live)[slot] == 0) return;      // uniform over the workgroup
     const float *prev_g = at<float>(ws, L.prev_g);
     const float *Sj = at<float>(ws, L.S) + int64_t(slot) * L.np;
     const float *Yj = at<float>(ws, L.Y) + int64_t(slot) * L.np;
@@ -156,56 +155,72 @@ __global__ __launch_bounds__(LB_BLOCK) void k_dots(char *__restrict__ ws, int n,
     }
 }
 
-// ---- k_scalars: one workgroup of 64 threads
-// `ldsn` > 0: the live part of S.Y^T is staged (in logical order) into ldsn x ldsn doubles of dynamic LDS, so
-// that a step of the sequential loops waits on LDS instead of on L2.
-__global__ __launch_bounds__(64) void k_scalars(char *__restrict__ ws, int n, int hist, int first, int ldsn) {
-    extern __shared__ double SYl[];
-    __shared__ double al[LB_MAX_HISTORY + 1], cc[LB_MAX_HISTORY + 1], pd[(LB_MAX_HISTORY + 1) * LB_NDOT];
-    __shared__ double Ak[LB_MAX_HISTORY + 1], rok[LB_MAX_HISTORY + 1], bk[LB_MAX_HISTORY + 1];
-    __shared__ int sord[LB_MAX_HISTORY + 1];
+// ---- k_scalars: one workgroup of LB_BLOCK threads.
+// The parallel parts (folding the partials, the new Gram row/column, staging, the y.(Hq) products) use all four
+// waves; the two sequential loops run on wave 0 alone, with no LDS round trip and no barrier on their critical
+// path: lane l owns the rows k = l, l+64, ... and keeps their partial sums in registers ("right-looking" form);
+// a step computes ONE scalar on its owner lane, v_readlane broadcasts it, and every lane folds it into its own
+// rows.  (The textbook left-looking form needs a wave-wide float64 reduction per step.)  The columns (first
+// loop) / rows (second loop) of S.Y^T that a run of steps needs are staged by all waves, in logical order, into
+// a panel of `pcols` x ldc doubles of dynamic LDS; history 50 fits one panel, history 150 takes two.
+__device__ inline double readlane_f64(double v, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, l), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+template <int NK>       // rows of the history per lane of wave 0: 1 up to history 63, 5 up to LB_MAX_HISTORY
+__global__ __launch_bounds__(LB_BLOCK) void k_scalars(char *__restrict__ ws, int n, int hist, int first, int pcols, int whole) {
+    extern __shared__ double panel[];
+    __shared__ double al[LB_MAX_HISTORY + 1], cc[LB_MAX_HISTORY + 1], Ak[LB_MAX_HISTORY + 1];
+    __shared__ double rok[LB_MAX_HISTORY + 1], bk[LB_MAX_HISTORY + 1], ck[LB_MAX_HISTORY + 1];
+    __shared__ double pd[(LB_MAX_HISTORY + 1) * LB_NDOT];       // folded partials; later: the 4 part sums of y.(Hq)
+    __shared__ int sord[LB_MAX_HISTORY + 1], snew[LB_MAX_HISTORY + 1];
     const LbLayout L = lb_layout(n, hist);
     int *hdr = at<int>(ws, L.hdr);
     int *ord = at<int>(ws, L.ord);
+    int *livef = at<int>(ws, L.live);
     double *Hp = at<double>(ws, L.H), *ro = at<double>(ws, L.ro), *b = at<double>(ws, L.b), *c = at<double>(ws, L.c);
     double *SY = at<double>(ws, L.SY), *YY = at<double>(ws, L.YY);
     double *coefY = at<double>(ws, L.coefY), *coefS = at<double>(ws, L.coefS);
     const double *part = at<double>(ws, L.part);
-    const int lane = threadIdx.x, slots = L.slots;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, slots = L.slots;
+    const int ldc = slots | 1;
 
     int count = first ? 0 : hdr[0];
     int cand = first ? 0 : hdr[1];
     double H = first ? 1.0 : Hp[0];
     int accept = 0;
-    for (int k = lane; k < count; k += 64) sord[k] = ord[k];
+    for (int k = tid; k < count; k += LB_BLOCK) sord[k] = ord[k];
     __syncthreads();
 
     if (!first) {
         // fold the per-chunk partials of every live row and of the candidate, in chunk order
-        for (int r = lane; r <= count; r += 64) {
+        for (int idx = tid; idx < (count + 1) * LB_NDOT; idx += LB_BLOCK) {
+            const int r = idx / LB_NDOT, k = idx - r * LB_NDOT;
             const int slot = r < count ? sord[r] : cand;
-            double a[LB_NDOT] = {0, 0, 0, 0, 0};
-            for (int ch = 0; ch < L.nchunk; ++ch)
-                for (int k = 0; k < LB_NDOT; ++k) a[k] += part[(int64_t(slot) * L.nchunk + ch) * LB_NDOT + k];
-            for (int k = 0; k < LB_NDOT; ++k) pd[r * LB_NDOT + k] = a[k];
+            const double *p = part + int64_t(slot) * L.nchunk * LB_NDOT + k;
+            double a = 0.0;
+            for (int ch = 0; ch < L.nchunk; ++ch) a += p[ch * LB_NDOT];
+            pd[idx] = a;
         }
         __syncthreads();
         const double ys = pd[count * LB_NDOT + 2], yy = pd[count * LB_NDOT + 4];
         accept = (float)ys > 1e-10f;
         // s_j.g and y_j.g of the live rows
-        for (int r = lane; r < count; r += 64) {
+        for (int r = tid; r < count; r += LB_BLOCK) {
             b[sord[r]] = pd[r * LB_NDOT + 0];
             c[sord[r]] = pd[r * LB_NDOT + 1];
         }
         if (accept) {
-            for (int r = lane; r < count; r += 64) {
+            for (int r = tid; r < count; r += LB_BLOCK) {
                 const int j = sord[r];
                 SY[int64_t(j) * slots + cand] = pd[r * LB_NDOT + 2];
                 SY[int64_t(cand) * slots + j] = pd[r * LB_NDOT + 3];
                 YY[int64_t(j) * slots + cand] = pd[r * LB_NDOT + 4];
                 YY[int64_t(cand) * slots + j] = pd[r * LB_NDOT + 4];
             }
-            if (lane == 0) {
+            if (tid == 0) {
                 SY[int64_t(cand) * slots + cand] = ys;
                 YY[int64_t(cand) * slots + cand] = yy;
                 ro[cand] = 1.0 / ys;
@@ -213,138 +228,217 @@ __global__ __launch_bounds__(64) void k_scalars(char *__restrict__ ws, int n, in
                 c[cand] = pd[count * LB_NDOT + 1];
             }
             H = ys / yy;
-            __syncthreads();
             // history bookkeeping: drop the oldest pair when full; its slot becomes the next free one
             int freed;
             if (count == hist) {
                 freed = sord[0];
-                __syncthreads();
-                int keep[(LB_MAX_HISTORY + 63) / 64];
-                int m = 0;
-                for (int k = lane; k + 1 < count; k += 64) keep[m++] = sord[k + 1];
-                __syncthreads();
-                m = 0;
-                for (int k = lane; k + 1 < count; k += 64) sord[k] = keep[m++];
-                if (lane == 0) sord[count - 1] = cand;
+                for (int k = tid; k + 1 < count; k += LB_BLOCK) snew[k] = sord[k + 1];
+                if (tid == 0) snew[count - 1] = cand;
             } else {
-                if (lane == 0) sord[count] = cand;
+                for (int k = tid; k < count; k += LB_BLOCK) snew[k] = sord[k];
+                if (tid == 0) snew[count] = cand;
                 ++count;
                 freed = count;            // slots are handed out in order 0,1,2,... until the ring is full
             }
+            __syncthreads();
+            for (int k = tid; k < count; k += LB_BLOCK) sord[k] = snew[k];
             cand = freed;
         }
         __syncthreads();
     }
 
-    // two-loop recursion on scalars.  Logical k = 0 oldest .. count-1 newest, j = sord[k].
-    const bool staged = ldsn >= count && ldsn > 0;
-    if (staged)
-        // eight loads in flight per lane (one at a time, every L2 round trip is on the critical path)
-        for (int base = lane; base < count * count; base += 64 * 8) {
+    for (int k = tid; k < count; k += LB_BLOCK) {
+        const int j = sord[k];
+        rok[k] = ro[j];
+        bk[k] = b[j];
+        ck[k] = c[j];
+    }
+    __syncthreads();
+
+    // stage `nl` lines of a Gram matrix G (columns m when `cols`, rows otherwise) starting at logical index m0:
+    // dst[(m - m0) * ldc + k] = G[k][m] (cols) or G[m][k] (rows), k < count, logical indices; threads t0, t0+nt, ...
+    // of the workgroup take part; eight loads in flight per thread
+    auto stage = [&](const double *G, double *dst, int m0, int nl, bool cols, int t0, int nt) {
+        const int tot = nl * count;
+        for (int base = tid - t0; base < tot; base += nt * 8) {
             double v[8];
-            int dst[8];
+            int di[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int idx = base + 64 * u;
-                const int k = idx < count * count ? idx / count : 0, m = idx < count * count ? idx - k * count : 0;
-                dst[u] = idx < count * count ? k * ldsn + m : -1;
-                v[u] = SY[int64_t(sord[k]) * slots + sord[m]];
+                const int idx = base + nt * u;
+                const bool ok = idx < tot;
+                const int mm = ok ? idx / count : 0, k = ok ? idx - mm * count : 0;
+                di[u] = ok ? mm * ldc + k : -1;
+                const int jm = sord[m0 + mm], jk = sord[k];
+                v[u] = cols ? G[int64_t(jk) * slots + jm] : G[int64_t(jm) * slots + jk];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (dst[u] >= 0) SYl[dst[u]] = v[u];
+                if (di[u] >= 0) dst[di[u]] = v[u];
         }
-    for (int k = lane; k < count; k += 64) {
-        rok[k] = ro[sord[k]];
-        bk[k] = b[sord[k]];
-    }
-    __syncthreads();
-    // Both loops are run "right-looking": lane l owns the rows k = l, l+64, ... and keeps their partial sums in
-    // registers; a step computes ONE scalar on its owner lane, publishes it through LDS, and every lane folds
-    // it into its own rows.  (The textbook left-looking form needs a wave-wide float64 reduction per step:
-    // twelve cross-lane shuffles on the critical path of each of the 2*count steps.)
-    constexpr int NK = (LB_MAX_HISTORY + 64) / 64;      // rows per lane, at most
-    auto sy = [&](int k, int m) -> double {             // s_k . y_m, logical indices
-        return staged ? SYl[k * ldsn + m] : SY[int64_t(sord[k]) * slots + sord[m]];
     };
-    double acc[NK];
+
     const int nk = (count + 63) >> 6;                   // rows per lane actually in use (wave-uniform)
-    //   al_m = ro_m ( -s_m.g - sum_{m'>m} al_m' s_m.y_m' ),  m = count-1 .. 0
+    double acc[NK], alr[NK], own_ro[NK], own_b[NK];
 #pragma unroll
-    for (int i = 0; i < NK; ++i) acc[i] = 0.0;
-    for (int m = count - 1; m >= 0; --m) {
-        if (lane == (m & 63)) {
-            double a = 0.0;
-#pragma unroll
-            for (int i = 0; i < NK; ++i) a = (i == (m >> 6)) ? acc[i] : a;
-            al[m] = rok[m] * (-bk[m] - a);
-        }
-        __syncthreads();
-        const double alm = al[m];
-#pragma unroll
-        for (int i = 0; i < NK; ++i) {
-            const int k = lane + 64 * i;
-            if (i < nk && k < m) acc[i] = fma(alm, sy(k, m), acc[i]);
-        }
+    for (int i = 0; i < NK; ++i) {
+        const int k = lane + 64 * i;
+        acc[i] = 0.0;
+        alr[i] = 0.0;
+        own_ro[i] = k < count ? rok[k] : 0.0;
+        own_b[i] = k < count ? bk[k] : 0.0;
     }
-    __syncthreads();
+    // one run of steps of the first loop on wave 0:  al_m = ro_m ( -s_m.g - sum_{m'>m} al_m' s_m.y_m' ),  m = mhi-1 .. mlo
+    auto loop1 = [&](const double *pan, int mlo, int mhi) {
+        for (int m = mhi - 1; m >= mlo; --m) {
+            const int ol = __builtin_amdgcn_readfirstlane(m & 63), oi = __builtin_amdgcn_readfirstlane(m >> 6);
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) mine = (i == oi) ? own_ro[i] * (-own_b[i] - acc[i]) : mine;
+            const double alm = readlane_f64(mine, ol);
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = lane + 64 * i;
+                if (i == oi && lane == ol) alr[i] = alm;
+                if (i < nk && k < m) acc[i] = fma(alm, pan[(m - mlo) * ldc + k], acc[i]);
+            }
+        }
+    };
+    double own_A[NK], ccr[NK];
+    //   cc_m = al_m - ro_m (A_m + sum_{m'<m} cc_m' s_m'.y_m),  m = mlo .. mhi-1
+    auto loop2 = [&](const double *pan, int mlo, int mhi) {
+        for (int m = mlo; m < mhi; ++m) {
+            const int ol = __builtin_amdgcn_readfirstlane(m & 63), oi = __builtin_amdgcn_readfirstlane(m >> 6);
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) mine = (i == oi) ? alr[i] - own_ro[i] * (own_A[i] + acc[i]) : mine;
+            const double ccm = readlane_f64(mine, ol);
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = lane + 64 * i;
+                if (i == oi && lane == ol) ccr[i] = ccm;
+                if (i < nk && k > m && k < count) acc[i] = fma(ccm, pan[(m - mlo) * ldc + k], acc[i]);
+            }
+        }
+    };
+    auto publish_al = [&]() {
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const int k = lane + 64 * i;
+                if (k < count) al[k] = alr[i];
+            }
+        }
+    };
     //   be_k = ro_j y_j.r_k,  r_k = H(-g - sum_m al_m y_m) + sum_{m<k} cc_m s_m,  cc_k = al_k - be_k
-    //   the y_j.(H q) part does not depend on earlier steps: all k in parallel first
-    for (int k = lane; k < count; k += 64) {
-        const int j = sord[k];
-        double a = 0.0;
-        for (int m0 = 0; m0 < count; m0 += 8) {
-            double v[8];
+    //   the y_j.(H q) part A_k does not depend on earlier steps: all k at once, four threads per row (m = part, part+4,
+    //   ...), the four sums folded in a fixed order.  `yy`: Y.Y^T staged in LDS by rows, or NULL (read through L2)
+    auto fold_A = [&](const double *yy) {
+        for (int k = tid >> 2; k < count; k += LB_BLOCK / 4) {
+            const int j = sord[k], pt = tid & 3;
+            double a = 0.0;
+            if (yy) {
+                for (int m = pt; m < count; m += 4) a = fma(al[m], yy[k * ldc + m], a);
+            } else {
+                for (int m0 = pt; m0 < count; m0 += 32) {
+                    double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = YY[int64_t(j) * slots + sord[m0 + u < count ? m0 + u : 0]];
+                    for (int u = 0; u < 8; ++u) v[u] = YY[int64_t(j) * slots + sord[m0 + 4 * u < count ? m0 + 4 * u : 0]];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (m0 + u < count) a = fma(al[m0 + u], v[u], a);
-        }
-        Ak[k] = H * (-c[j] - a);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NK; ++i) acc[i] = 0.0;
-    for (int m = 0; m < count; ++m) {
-        if (lane == (m & 63)) {
-            double e = 0.0;
-#pragma unroll
-            for (int i = 0; i < NK; ++i) e = (i == (m >> 6)) ? acc[i] : e;
-            cc[m] = al[m] - rok[m] * (Ak[m] + e);
+                    for (int u = 0; u < 8; ++u)
+                        if (m0 + 4 * u < count) a = fma(al[m0 + 4 * u], v[u], a);
+                }
+            }
+            pd[k * 4 + pt] = a;
         }
         __syncthreads();
-        const double ccm = cc[m];
+        for (int k = tid; k < count; k += LB_BLOCK)
+            Ak[k] = H * (-ck[k] - ((pd[k * 4] + pd[k * 4 + 1]) + (pd[k * 4 + 2] + pd[k * 4 + 3])));
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
             const int k = lane + 64 * i;
-            if (i < nk && k > m && k < count) acc[i] = fma(ccm, sy(m, k), acc[i]);
+            acc[i] = 0.0;
+            ccr[i] = 0.0;
+            own_A[i] = k < count ? Ak[k] : 0.0;
+        }
+    };
+
+    if (whole) {
+        // everything fits: three images (columns of S.Y^T, its rows, Y.Y^T).  While wave 0 runs the first loop the
+        // other three waves stage what the rest needs.
+        double *pan2 = panel + pcols * ldc, *yyl = pan2 + pcols * ldc;
+        stage(SY, panel, 0, count, true, 0, LB_BLOCK);
+        __syncthreads();
+        if (wave == 0) {
+            loop1(panel, 0, count);
+        } else {
+            stage(SY, pan2, 0, count, false, 64, LB_BLOCK - 64);
+            stage(YY, yyl, 0, count, false, 64, LB_BLOCK - 64);
+        }
+        publish_al();
+        __syncthreads();
+        fold_A(yyl);
+        if (wave == 0) loop2(pan2, 0, count);
+    } else {
+        for (int mhi = count; mhi > 0; mhi -= pcols) {
+            const int mlo = mhi > pcols ? mhi - pcols : 0;
+            __syncthreads();                                // the previous panel is no longer read
+            stage(SY, panel, mlo, mhi - mlo, true, 0, LB_BLOCK);
+            __syncthreads();
+            if (wave == 0) loop1(panel, mlo, mhi);
+        }
+        publish_al();
+        __syncthreads();
+        fold_A(nullptr);
+        for (int mlo = 0; mlo < count; mlo += pcols) {
+            const int mhi = mlo + pcols < count ? mlo + pcols : count;
+            __syncthreads();
+            stage(SY, panel, mlo, mhi - mlo, false, 0, LB_BLOCK);
+            __syncthreads();
+            if (wave == 0) loop2(panel, mlo, mhi);
         }
     }
-    __syncthreads();
-    for (int k = lane; k < count; k += 64) {
-        coefY[k] = -H * al[k];
-        coefS[k] = cc[k];
-        ord[k] = sord[k];
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int k = lane + 64 * i;
+            if (k < count) {
+                coefY[k] = -H * alr[i];
+                coefS[k] = ccr[i];
+            }
+        }
     }
-    if (lane == 0) {
+    for (int sl = tid; sl < slots; sl += LB_BLOCK) livef[sl] = 0;
+    __syncthreads();
+    for (int k = tid; k < count; k += LB_BLOCK) {
+        ord[k] = sord[k];
+        livef[sord[k]] = 1;
+    }
+    if (tid == 0) {
         coefY[slots] = -H;     // coefficient of g
         hdr[0] = count;
         hdr[1] = cand;
         hdr[2] = accept;
+        hdr[3] = 0;            // ticket of k_combine's last-block fold
         Hp[0] = H;
     }
 }
 
-// ---- k_combine: grid (ncomb), one element per thread.  `newest` = physical slot of the just-accepted pair
-// (its values are still in registers here; this kernel stores them)
+// ---- k_combine: grid (ncomb), 64 elements per workgroup: wave w sums the stored rows k = w, w+4, ... of its element
+// (four times as many loads in flight as one thread per element would have), wave 0 adds the four sums in a fixed order
+// and finishes the element.  `newest` = physical slot of the just-accepted pair (its values are still in registers here;
+// this kernel stores them)
 __global__ __launch_bounds__(LB_BLOCK) void k_combine(char *__restrict__ ws, int n, int hist, const float *__restrict__ g,
-                                                      float *__restrict__ d, float t, int first) {
+                                                      float *__restrict__ d, float t, int first, float *__restrict__ stats,
+                                                      float *__restrict__ x, float *__restrict__ x0, float t_next) {
     __shared__ double red[(LB_BLOCK / 64) * 4];
+    __shared__ int last_block;
     __shared__ double cY[LB_MAX_HISTORY], cS[LB_MAX_HISTORY];
+    __shared__ double psum[3][64];
     __shared__ int sord[LB_MAX_HISTORY];
     const LbLayout L = lb_layout(n, hist);
-    const int *hdr = at<int>(ws, L.hdr);
+    int *hdr = at<int>(ws, L.hdr);
     const int *ord = at<int>(ws, L.ord);
     const int count = hdr[0], accept = hdr[2];
     const double *coefY = at<double>(ws, L.coefY), *coefS = at<double>(ws, L.coefS);
@@ -360,32 +454,39 @@ __global__ __launch_bounds__(LB_BLOCK) void k_combine(char *__restrict__ ws, int
     float *prev_g = at<float>(ws, L.prev_g);
     float *S = at<float>(ws, L.S), *Y = at<float>(ws, L.Y);
     double st[4] = {0, 0, 0, 0};    // g.d, sum|g|, max|d|, max|g|
-    const int i = blockIdx.x * LB_BLOCK + threadIdx.x;
+    const int wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    double acc = 0.0;
     if (i < n) {
-        const float gi = g[i];
-        const float yc = first ? 0.f : gi - prev_g[i];
-        const float sc = first ? 0.f : d[i] * t;
-        double acc = cG * (double)gi;
-        int k = 0;
-        for (; k + 4 <= stored; k += 4) {               // 8 independent loads in flight
+        int k = wv;
+        for (; k + 12 < stored; k += 16) {              // 8 independent loads in flight
             float yv[4], sv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int64_t row = int64_t(sord[k + u]) * L.np + i;
+                const int64_t row = int64_t(sord[k + 4 * u]) * L.np + i;
                 yv[u] = Y[row];
                 sv[u] = S[row];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                acc = fma(cY[k + u], (double)yv[u], acc);
-                acc = fma(cS[k + u], (double)sv[u], acc);
+                acc = fma(cY[k + 4 * u], (double)yv[u], acc);
+                acc = fma(cS[k + 4 * u], (double)sv[u], acc);
             }
         }
-        for (; k < stored; ++k) {
+        for (; k < stored; k += 4) {
             const int64_t row = int64_t(sord[k]) * L.np + i;
             acc = fma(cY[k], (double)Y[row], acc);
             acc = fma(cS[k], (double)S[row], acc);
         }
+    }
+    if (wv > 0) psum[wv - 1][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (wv == 0 && i < n) {
+        const float gi = g[i];
+        const float yc = first ? 0.f : gi - prev_g[i];
+        const float sc = first ? 0.f : d[i] * t;
+        const int e = threadIdx.x;
+        acc = cG * (double)gi + ((acc + psum[0][e]) + (psum[1][e] + psum[2][e]));
         if (newest >= 0) {
             acc = fma(cY[count - 1], (double)yc, acc);
             acc = fma(cS[count - 1], (double)sc, acc);
@@ -395,6 +496,11 @@ __global__ __launch_bounds__(LB_BLOCK) void k_combine(char *__restrict__ ws, int
         const float di = (float)acc;
         d[i] = di;
         prev_g[i] = gi;
+        if (x) {                                        // the line search's first trial point, x0 kept for the others
+            const float xi = x[i];
+            x0[i] = xi;
+            x[i] = xi + t_next * di;
+        }
         st[0] = (double)gi * (double)di;
         st[1] = fabs((double)gi);
         st[2] = fabs((double)di);
@@ -404,26 +510,28 @@ __global__ __launch_bounds__(LB_BLOCK) void k_combine(char *__restrict__ ws, int
     if (threadIdx.x == 0) {
         double *p = at<double>(ws, L.spart) + int64_t(blockIdx.x) * 4;
         p[0] = st[0]; p[1] = st[1]; p[2] = st[2]; p[3] = st[3];
+        // the workgroup that takes the last ticket folds everybody's partials (in index order: the result does
+        // not depend on which workgroup that is)
+        __threadfence();
+        last_block = atomicAdd(&hdr[3], 1) == (int)gridDim.x - 1;
     }
-}
-
-// one wave: lane l folds partials l, l+64, ... in order, then the lanes are folded in a fixed tree
-__global__ __launch_bounds__(64) void k_stats(const char *__restrict__ ws, int n, int hist, float *__restrict__ stats) {
-    const LbLayout L = lb_layout(n, hist);
+    __syncthreads();
+    if (!last_block || threadIdx.x >= 64) return;
+    __threadfence();
+    // one wave: lane l folds partials l, l+64, ... in order, then the lanes are folded in a fixed tree
     const double *p = reinterpret_cast<const double *>(ws + L.spart);
     double a0 = 0, a1 = 0, m2 = 0, m3 = 0;
     for (int ch = threadIdx.x; ch < L.ncomb; ch += 64) {
-        a0 += p[ch * 4 + 0];
-        a1 += p[ch * 4 + 1];
-        m2 = fmax(m2, p[ch * 4 + 2]);
-        m3 = fmax(m3, p[ch * 4 + 3]);
+        a0 += __hip_atomic_load(p + ch * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a1 += __hip_atomic_load(p + ch * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m2 = fmax(m2, __hip_atomic_load(p + ch * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        m3 = fmax(m3, __hip_atomic_load(p + ch * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
     m2 = wave_max(m2);
     m3 = wave_max(m3);
     if (threadIdx.x != 0) return;
-    const int *hdr = reinterpret_cast<const int *>(ws + L.hdr);
     stats[0] = (float)a0;           // g.d
     stats[1] = (float)a1;           // sum |g|
     stats[2] = (float)m2;           // max |d|
@@ -432,15 +540,19 @@ __global__ __launch_bounds__(64) void k_stats(const char *__restrict__ ws, int n
     stats[5] = (float)reinterpret_cast<const double *>(ws + L.H)[0];
     stats[6] = (float)hdr[2];       // the last pair was accepted
     stats[7] = 0.f;
+    hdr[3] = 0;
 }
 
 // out = [loss, g.d, max|g|, sum|g|] after one closure evaluation of the line search
 __global__ __launch_bounds__(1024) void k_lbfgs_eval_stats(const float *__restrict__ g, const float *__restrict__ d, int n,
-                                                           const float *__restrict__ loss, float *__restrict__ out) {
+                                                           const float *__restrict__ loss, float *__restrict__ out,
+                                                           float *__restrict__ g_copy, const float *__restrict__ stats8,
+                                                           float *host13, int ticket) {
     __shared__ double red[16 * 3];
     double s0 = 0, s1 = 0, m = 0;
     for (int i = threadIdx.x; i < n; i += 1024) {
         const float gi = g[i];
+        if (g_copy) g_copy[i] = gi;
         s0 = fma((double)gi, (double)d[i], s0);
         s1 += fabs((double)gi);
         m = fmax(m, fabs((double)gi));
@@ -461,10 +573,25 @@ __global__ __launch_bounds__(1024) void k_lbfgs_eval_stats(const float *__restri
             s1 += red[i * 3 + 1];
             m = fmax(m, red[i * 3 + 2]);
         }
-        out[0] = loss ? loss[0] : 0.f;
-        out[1] = (float)s0;
-        out[2] = (float)m;
-        out[3] = (float)s1;
+        const float o0 = loss ? loss[0] : 0.f, o1 = (float)s0, o2 = (float)m, o3 = (float)s1;
+        out[0] = o0;
+        out[1] = o1;
+        out[2] = o2;
+        out[3] = o3;
+        if (host13) {
+            // the host's copy, in pinned host memory: the direction's statistics (an earlier launch of this stream
+            // wrote them), this evaluation's, then - after a system-scope fence - the ticket the host polls for
+            if (stats8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) host13[k] = stats8[k];
+            }
+            host13[8] = o0;
+            host13[9] = o1;
+            host13[10] = o2;
+            host13[11] = o3;
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<int *>(host13) + 12, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -481,9 +608,10 @@ int64_t pinn_lbfgs_workspace_floats(int64_t n, int32_t history) {
     return lb_layout(n, history).total / 4;
 }
 
-int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const float *g, float *d, float t,
-                         int32_t first, float *stats8, void *stream) {
+int pinn_lbfgs_direction_advance(float *workspace, int64_t n, int32_t history, const float *g, float *d, float t,
+                                 int32_t first, float *stats8, float *x, float *x0, float t_next, void *stream) {
     if (!workspace || !g || !d || !stats8) return PINN_ERR_NULL;
+    if ((x == nullptr) != (x0 == nullptr)) return PINN_ERR_NULL;
     if (bad_sizes(n, history)) return PINN_ERR_INVALID_DESC;
     if ((reinterpret_cast<uintptr_t>(workspace) & 7) != 0) return PINN_ERR_INVALID_DESC;
     const LbLayout L = lb_layout(n, history);
@@ -491,19 +619,52 @@ int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const flo
     hipStream_t s = (hipStream_t)stream;
     if (!first)
         hipLaunchKernelGGL(k_dots, dim3(L.nchunk, L.slots), dim3(LB_BLOCK), 0, s, ws, (int)n, (int)history, g, d, t);
-    const int ldsn = (history + 1) * (history + 1) * 8 <= 40 * 1024 ? history + 1 : 0;   // static LDS of k_scalars: 22 KB
-    hipLaunchKernelGGL(k_scalars, dim3(1), dim3(64), size_t(ldsn) * ldsn * 8, s, ws, (int)n, (int)history, (int)first,
-                       ldsn);
-    hipLaunchKernelGGL(k_combine, dim3(L.ncomb), dim3(LB_BLOCK), 0, s, ws, (int)n, (int)history, g, d, t, (int)first);
-    hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, s, ws, (int)n, (int)history, stats8);
+    // panel of k_scalars: as many lines of S.Y^T as fit 96 KB of dynamic LDS (its static arrays take 31 KB)
+    // (or, when three whole images fit - history <= 72 - all of S.Y^T by columns, by rows, and Y.Y^T)
+    const int ldc = L.slots | 1;
+    int pcols = (96 * 1024) / (ldc * 8);
+    if (pcols > L.slots) pcols = L.slots;
+    const int whole = size_t(3) * L.slots * ldc * 8 <= 128 * 1024;
+    const size_t dyn = size_t(whole ? 3 : 1) * pcols * ldc * 8;
+    auto kern = L.slots <= 64 ? k_scalars<1> : k_scalars<(LB_MAX_HISTORY + 64) / 64>;
+    if (dyn > 32 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        (void)hipGetLastError();
+        return PINN_ERR_HIP;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(LB_BLOCK), dyn, s, ws, (int)n, (int)history, (int)first, pcols, whole);
+    hipLaunchKernelGGL(k_combine, dim3(L.ncomb), dim3(LB_BLOCK), 0, s, ws, (int)n, (int)history, g, d, t, (int)first,
+                       stats8, x, x0, t_next);
+    return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+}
+
+int pinn_lbfgs_direction(float *workspace, int64_t n, int32_t history, const float *g, float *d, float t,
+                         int32_t first, float *stats8, void *stream) {
+    return pinn_lbfgs_direction_advance(workspace, n, history, g, d, t, first, stats8, nullptr, nullptr, 0.f, stream);
+}
+
+int pinn_lbfgs_eval_stats_keep(const float *g, const float *d, int64_t n, const float *loss, float *out4, float *g_copy,
+                               const float *stats8, float *host13, int32_t ticket, void *stream) {
+    if (!g || !d || !out4) return PINN_ERR_NULL;
+    if (n <= 0 || n > (int64_t(1) << 24)) return PINN_ERR_INVALID_DESC;
+    hipLaunchKernelGGL(k_lbfgs_eval_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, d, (int)n, loss, out4, g_copy,
+                       stats8, host13, (int)ticket);
     return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
 }
 
 int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float *loss, float *out4, void *stream) {
-    if (!g || !d || !out4) return PINN_ERR_NULL;
-    if (n <= 0 || n > (int64_t(1) << 24)) return PINN_ERR_INVALID_DESC;
-    hipLaunchKernelGGL(k_lbfgs_eval_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, d, (int)n, loss, out4);
-    return hipGetLastError() == hipSuccess ? PINN_OK : PINN_ERR_HIP;
+    return pinn_lbfgs_eval_stats_keep(g, d, n, loss, out4, nullptr, nullptr, nullptr, 0, stream);
+}
+
+int pinn_host_device_pointer(void *host, void **device) {
+    if (!host || !device) return PINN_ERR_NULL;
+    *device = nullptr;
+    if (hipHostGetDevicePointer(device, host, 0) != hipSuccess || !*device) {
+        (void)hipGetLastError();
+        *device = nullptr;
+        return PINN_ERR_HIP;
+    }
+    return PINN_OK;
 }
 
 }  // extern "C"

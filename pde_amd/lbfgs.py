@@ -10,9 +10,10 @@ trajectory of `torch.optim.LBFGS` up to float32 summation order) arranged differ
 
   * parameters and gradients are ONE flat buffer each (`p.grad` are views, so the closure's
     `loss.backward()` accumulates straight into it — no gather/scatter ops);
-  * the direction update is one kernel launch (`pinn_lbfgs_direction`, csrc/lbfgs.hip);
-  * each closure evaluation is followed by one launch that packs [loss, g.d, max|g|] and ONE
-    device->host read; all line-search arithmetic runs on Python floats.
+  * the direction update is one call of three launches (`pinn_lbfgs_direction_advance`, csrc/lbfgs.hip), the
+    last of which also moves the weights to the line search's first trial point;
+  * each closure evaluation is followed by one launch that packs [loss, g.d, max|g|] and keeps a copy of the
+    gradient, and ONE device->host copy; all line-search arithmetic runs on Python floats.
 
 There is no CPU fallback in the product: without the HIP library the constructor raises.
 (`kernels=` is the seam tests/ uses to drive the host logic on the CPU.)
@@ -105,6 +106,7 @@ class LBFGS(torch.optim.Optimizer):
         st.setdefault("n_iter", 0)
         self.host_syncs = 0
         self._x_at = None
+        self._x0 = None                     # the line search's starting point when the direction launch saves it
 
     # ---- flat gradient -------------------------------------------------------------------
     def _intact(self):
@@ -148,9 +150,19 @@ class LBFGS(torch.optim.Optimizer):
             off += n
         return self._g
 
+    def _fetch(self, ev):
+        """(stats8, out4) through the kernels' pinned-host mirror when `ev` is what their last statistics launch wrote"""
+        fetch = getattr(self._k, "fetch", None)
+        if fetch is None or ev is not getattr(self._k, "out", None):
+            return None
+        return fetch()
+
     def _read(self, dev_vec):
         """device floats -> Python floats: the one blocking read per evaluation."""
         self.host_syncs += 1
+        got = self._fetch(dev_vec)
+        if got is not None:
+            return got[1]
         if self._host is None:
             return [float(v) for v in dev_vec.tolist()]
         k = dev_vec.numel()
@@ -159,25 +171,38 @@ class LBFGS(torch.optim.Optimizer):
         return self._host[:k].tolist()
 
     def _read2(self, a, b):
-        """two device vectors, ONE blocking read"""
+        """two device vectors, ONE blocking read (and one copy when they lie side by side, as the native kernels'
+        statistics do)"""
         self.host_syncs += 1
         if self._host is None:
             return [float(v) for v in a.tolist()], [float(v) for v in b.tolist()]
+        if a is getattr(self._k, "stats", None):
+            got = self._fetch(b)
+            if got is not None:
+                return got
         ka, kb = a.numel(), b.numel()
-        self._host2[:ka].copy_(a, non_blocking=True)
-        self._host2[ka:ka + kb].copy_(b, non_blocking=True)
+        both = getattr(self._k, "both", None)
+        if both is not None and both.numel() == ka + kb and a.data_ptr() == both.data_ptr() \
+                and b.data_ptr() == both.data_ptr() + 4 * ka:
+            self._host2[:ka + kb].copy_(both, non_blocking=True)
+        else:
+            self._host2[:ka].copy_(a, non_blocking=True)
+            self._host2[ka:ka + kb].copy_(b, non_blocking=True)
         torch.cuda.current_stream(a.device).synchronize()
         v = self._host2[:ka + kb].tolist()
         return v[:ka], v[ka:]
 
     # ---- one closure evaluation at x0 + t d ------------------------------------------------
-    def _evaluate_async(self, closure, x0, t):
-        """enqueue the evaluation; returns (flat gradient copy, device [f, g.d, max|g|, sum|g|]) without reading"""
-        torch.add(x0, self._d, alpha=t, out=self._x)
+    def _evaluate_async(self, closure, x0, t, moved=False):
+        """enqueue the evaluation; returns (flat gradient copy, device [f, g.d, max|g|, sum|g|]) without reading.
+        `moved`: the parameters already hold x0 + t d (the direction launch put them there)."""
+        if not moved:
+            torch.add(x0, self._d, alpha=t, out=self._x)
         self._x_at = t                      # the parameters now hold x0 + t d
         loss = closure()
         g = self._gather()
-        return g.clone(), self._k.eval_stats(g, self._d, loss)
+        keep = torch.empty_like(g)          # (no launch: the statistics launch fills it)
+        return keep, self._k.eval_stats(g, self._d, loss, keep)
 
     def _evaluate(self, closure, x0, t):
         g, ev = self._evaluate_async(closure, x0, t)
@@ -268,9 +293,15 @@ class LBFGS(torch.optim.Optimizer):
             n_iter += 1
             st["n_iter"] += 1
             first = st["n_iter"] == 1
-            dstats = self._k.direction(g, self._d, t, first)
             spec = x0 = None
-            if wolfe and not first and self.speculate:
+            speculating = wolfe and not first and self.speculate
+            if speculating:
+                if self._x0 is None:
+                    self._x0 = torch.empty_like(self._x)
+                dstats = self._k.direction(g, self._d, t, first, x=self._x, x0=self._x0, t_next=lr)
+            else:
+                dstats = self._k.direction(g, self._d, t, first)
+            if speculating:
                 # From the second iteration on the line search starts at t = lr whatever the direction's
                 # statistics say: that evaluation is enqueued before they are read, and both come back in ONE
                 # blocking read instead of two.  Decisions and evaluation counts are those of the plain order;
@@ -278,10 +309,10 @@ class LBFGS(torch.optim.Optimizer):
                 # iteration of a run) has one evaluation been made in vain.  It is undone: weights and flat
                 # gradient are put back, it is not counted in func_evals, and `on_discard` (if set) lets the
                 # closure's owner roll back its own side effects (PhysicsInformedNN: the iteration counter).
-                x0 = self._x.clone()
-                gs, ev = self._evaluate_async(closure, x0, lr)
+                x0 = self._x0
+                gs, ev = self._evaluate_async(closure, x0, lr, moved=True)
                 (gtd, gsum, dmax, _gm, _cnt, _hd, _, _), (fs, gtds, gmaxs, _) = self._read2(dstats, ev)
-                spec = _Point(lr, fs, gs, gtds, gmaxs)
+                spec = True
             else:
                 gtd, gsum, dmax, _gm, _cnt, _hd, _, _ = self._read(dstats)
             prev_f = f
@@ -293,10 +324,15 @@ class LBFGS(torch.optim.Optimizer):
                     if self.on_discard is not None:
                         self.on_discard()
                 break
-            if wolfe:
+            if spec is not None and not fs > f + 1e-4 * lr * gtd and abs(gtds) <= -0.9 * gtd:
+                # the usual case, without the search's bookkeeping: the first trial point satisfies both Wolfe
+                # conditions (the first two tests of _strong_wolfe with c1 = 1e-4, c2 = 0.9)
+                f, g, gmax, ls_evals = fs, gs, gmaxs, 1
+            elif wolfe:
                 if x0 is None:
                     x0 = self._x.clone()
-                pt, ls_evals = self._strong_wolfe(closure, x0, t, f, g, gtd, gmax, dmax, first_point=spec)
+                pt, ls_evals = self._strong_wolfe(closure, x0, t, f, g, gtd, gmax, dmax,
+                                                  first_point=_Point(lr, fs, gs, gtds, gmaxs) if spec is not None else None)
                 t, f, g, gmax = pt.t, pt.f, pt.g, pt.gmax
                 if self._x_at != t:         # (the accepted point is usually the last one evaluated: already there)
                     torch.add(x0, self._d, alpha=t, out=self._x)

@@ -281,6 +281,21 @@ class NetU(torch.nn.Sequential):
         leaf.grad = None
         self.distribute_flat_grad(g)
 
+    def flat_grad_view(self):
+        """The flat gradient buffer when every `.grad` is a consecutive float32 view of ONE buffer, in parameter order
+        (pde_amd.lbfgs.LBFGS and FusedAdam keep them so); None otherwise."""
+        params = self.param_list
+        first = params[0].grad
+        if first is None or first.dtype != torch.float32:
+            return None
+        base, off = first.data_ptr(), 0
+        for p in params:
+            gp = p.grad
+            if gp is None or gp.data_ptr() != base + 4 * off or not gp.is_contiguous():
+                return None
+            off += p.numel()
+        return first.as_strided((off,), (1,))
+
     def distribute_flat_grad(self, g):
         """Runs once per native op and backward pass: every parameter gets its slice of the op's flat gradient.  `.grad` is None (after zero_grad(set_to_none=True)): the
         slices become the `.grad` tensors, no kernel at all.  `.grad` are consecutive views of one

@@ -327,13 +327,16 @@ class PhysicsInformedNN:
                 "loss_s": loss_s, "loss_reg": self._reg_share()}
 
     @torch.no_grad()
-    def _loss_terms_direct(self, overlap=False):
+    def _loss_terms_direct(self, overlap=False, assign_grad=False):
         """The same closure without autograd.  Every term of the reference's loss enters with weight 1 and every
         native op here knows its own gradient, so `loss.backward()` is: the collocation pass (value + gradient in
-        one kernel), one cotangent launch + one net_u vjp per data term, and ONE add of the flat gradient into
-        `.grad` — no graph, no ones / multiply / accumulate launches, a third of the host time of the autograd
-        form (`closure_impl = "autograd"` selects that one; both are held to the reference's backward() by the
-        same tests).  The list-of-terms loss_s (broadcasting targets) stays on autograd."""
+        one kernel), one cotangent launch + one net_u vjp per data term, and ONE launch (pinn_closure_sum) that
+        adds the terms up in the reference's order and the two flat gradients into `.grad` — no graph, no ones /
+        multiply / accumulate launches, a third of the host time of the autograd form (`closure_impl = "autograd"`
+        selects that one; both are held to the reference's backward() by the same tests).  The list-of-terms
+        loss_s (broadcasting targets) stays on autograd.
+        `assign_grad` (the captured L-BFGS closure): `.grad` is overwritten instead of added to, which saves the
+        zeroing launch in front of it."""
         v = self.variant
         dnn, eng = self.dnn, self.dnn.engine
         theta = dnn.flat_theta()
@@ -346,7 +349,7 @@ class PhysicsInformedNN:
             buf = torch.zeros(P + nf, dtype=torch.float32, device=theta.device)
             self.engine_f.loss_grad(theta, self.xf, self.tf, 1.0 / N, buf[P:], buf[:P])
             self.engine_f.last_sums = buf[P:]
-            return (buf[P] if nf == 1 else buf[P:].sum()) / N, buf[:P]
+            return buf
 
         side = cur = None
         if overlap and torch.device(self.device).type == "cuda":
@@ -354,46 +357,62 @@ class PhysicsInformedNN:
             side = _side_stream(self.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                loss_f, g_f = collocation()
+                buf = collocation()
         g = torch.zeros(P, dtype=torch.float32, device=theta.device)
+        # the data terms' values, in the order the reference adds them: loss0, loss_b, then loss1 | loss_prev | loss_s
+        # (a mean-square term writes its value and a 0 behind it, which the next term overwrites)
+        terms = torch.empty(8, dtype=torch.float32, device=theta.device)
         n0, nb = self.x0.shape[0], self.x_lb.shape[0]
         dirichlet = v.bc == "dirichlet"
         out = eng.forward(theta, self._X_data, None)
-        losses = data_loss_values(out, self._tgt0, n0, nb, dirichlet)
+        data_loss_values(out, self._tgt0, n0, nb, dirichlet, out_losses=terms[0:2])
         eng.forward_vjp(theta, self._X_data, None, data_loss_cot(out, self._tgt0, n0, nb, dirichlet, one, one), g)
-        loss0, loss_b = losses[0], losses[1]
-        loss = loss0 + loss_b
+        loss0, loss_b = terms[0], terms[1]
+        n_terms = 2
 
         def mse_term(X, tgt):
             o = eng.forward(theta, X, None)
-            val = data_loss_values(o, tgt, o.shape[0], 0, False)[0]
+            data_loss_values(o, tgt, o.shape[0], 0, False, out_losses=terms[n_terms:n_terms + 2])
             eng.forward_vjp(theta, X, None, data_loss_cot(o, tgt, o.shape[0], 0, False, one, one), g)
-            return val
+            return terms[n_terms]
 
         loss1, loss_prev, loss_s = None, 0, 0
         if v.style == "bc" and self.u1 is not None:
             loss1 = mse_term(self._X1, self._tgt1)
-            loss = loss + loss1
+            n_terms += 1
         if v.style == "sw" and self.X_prev is not None and self.X_prev.numel() > 0:
             loss_prev = mse_term(self.X_prev, self._tgt_prev)
-            loss = loss + loss_prev
+            n_terms += 1
         if getattr(self, "earliest_solutions", None):
+            if assign_grad:
+                raise RuntimeError("assign_grad: the autograd term loss_s accumulates into .grad on its own")
             with torch.enable_grad():
                 for X_ref, h_ref in self.earliest_solutions:
                     loss_s = loss_s + torch.mean(torch.square(dnn(X_ref) - h_ref))
                 loss_s.backward()
             loss_s = loss_s.detach()
-            loss = loss + loss_s
+            terms[n_terms].copy_(loss_s)
+            n_terms += 1
         if side is None:
-            loss_f, g_f = collocation()
+            buf = collocation()
         else:
             cur.wait_stream(side)
             if not torch.cuda.is_current_stream_capturing():
-                loss_f.record_stream(cur)
-                g_f.record_stream(cur)
-        g.add_(g_f)
-        dnn.distribute_flat_grad(g)
-        loss = loss + loss_f
+                buf.record_stream(cur)
+        flat = dnn.flat_grad_view() if theta.is_cuda else None
+        if flat is not None:
+            from ._native import closure_sum
+            loss2 = closure_sum(terms, n_terms, buf[P:], N, g, buf[:P], flat, accumulate=not assign_grad)
+            loss, loss_f = loss2[0], loss2[1]
+        else:
+            if assign_grad:
+                raise RuntimeError("assign_grad needs `.grad` to be consecutive views of one flat buffer")
+            loss_f = (buf[P] if nf == 1 else buf[P:].sum()) / N
+            g.add_(buf[:P])
+            dnn.distribute_flat_grad(g)
+            loss = loss0 + loss_b + loss_f
+            for k in range(2, n_terms):
+                loss = loss + terms[k]
         return {"loss": loss, "loss0": loss0, "loss_b": loss_b, "loss_f": loss_f, "loss1": loss1, "loss_prev": loss_prev,
                 "loss_s": loss_s, "loss_reg": self._reg_share()}
 
@@ -751,13 +770,15 @@ class PhysicsInformedNN:
                     done += 1
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
+
+            def body():
                 if self._fused_adam:
                     opt.flat_grad().zero_()             # the flat gradient is a static buffer: cleared inside the graph
                 terms = self._loss_terms(overlap=True)
                 opt.step()
+                return terms
+            graph, terms = self._capture(body)
         except Exception as ex:                         # noqa: BLE001
             torch.cuda.synchronize(self.device)
             if not self.hip_graph_fallback:
@@ -776,6 +797,32 @@ class PhysicsInformedNN:
         self._adam_graph = graph                        # keep the captured buffers alive with the model
         return done
 
+    def _capture(self, body):
+        """`body()` captured into a HIP graph: (graph, what body returned).  A capture can be invalidated by work that
+        is not its own (hipErrorStreamCaptureInvalidated was seen once in this round's GPU test runs, in a process where
+        models and their graphs come and go; not reproduced, cause not established).  Two precautions: the cyclic
+        garbage collector is paused for the duration, so that no older graph is destroyed and no device memory freed
+        inside the capture, and an invalidated capture is attempted once more before the error is raised — nothing
+        that was captured has run."""
+        import gc
+        last = None
+        for _ in range(2):
+            graph = torch.cuda.CUDAGraph()
+            gc.collect()
+            was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(graph):
+                    out = body()
+                return graph, out
+            except Exception as ex:                     # noqa: BLE001
+                last = ex
+                torch.cuda.synchronize(self.device)
+            finally:
+                if was_enabled:
+                    gc.enable()
+        raise last
+
     def _graph_closure(self):
         """The L-BFGS closure (zero the flat gradient, the loss terms, loss.backward()) captured once
         into a HIP graph and replayed per evaluation: the line search moves the weights in place, so
@@ -791,11 +838,17 @@ class PhysicsInformedNN:
                     self._loss_terms(overlap=True)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
             opt.zero_grad()
-            with torch.cuda.graph(graph):
+            # the direct closure writes `.grad` in its last launch: no zeroing launch in front of the kernels
+            assign = (self.group is None and self.closure_impl == "direct"
+                      and not getattr(self, "earliest_solutions", None) and self.dnn.flat_grad_view() is not None)
+
+            def body():
+                if assign:
+                    return self._loss_terms_direct(overlap=True, assign_grad=True)
                 opt.flat_grad().zero_()
-                terms = self._loss_terms(overlap=True)
+                return self._loss_terms(overlap=True)
+            graph, terms = self._capture(body)
         except Exception as ex:                         # noqa: BLE001
             torch.cuda.synchronize(self.device)
             if not self.hip_graph_fallback:

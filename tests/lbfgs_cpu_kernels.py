@@ -11,7 +11,14 @@ class CpuLBFGSKernels:
         self.H = 1.0
         self.prev_g = None
 
-    def direction(self, g, d, t, first):
+    def direction(self, g, d, t, first, x=None, x0=None, t_next=0.0):
+        r = self._direction(g, d, t, first)
+        if x is not None:
+            x0.copy_(x)
+            x.add_(d, alpha=t_next)
+        return r
+
+    def _direction(self, g, d, t, first):
         g = g.to(self.dtype)
         if first:
             self.S, self.Y, self.ro, self.H = [], [], [], 1.0
@@ -38,6 +45,8 @@ class CpuLBFGSKernels:
         return torch.tensor([float(g.dot(r)), float(g.abs().sum()), float(r.abs().max()), float(g.abs().max()),
                              float(len(self.S)), self.H, 0.0, 0.0], dtype=torch.float64)
 
-    def eval_stats(self, g, d, loss):
+    def eval_stats(self, g, d, loss, g_copy=None):
+        if g_copy is not None:
+            g_copy.copy_(g)
         return torch.tensor([float(loss), float(g.to(self.dtype).dot(d.to(self.dtype))), float(g.abs().max()),
                              float(g.abs().sum())], dtype=torch.float64)

@@ -8,11 +8,12 @@ and after Adam + 6 L-BFGS iterations (L = 6), each from a float32 run (the refer
   * Adam phase: distance to the float64 trajectory, relative to the distance travelled, at most 3x the reference's own
     float32 run's (which is 3e-6 ... 1.2e-5), and the same closure count;
   * Adam + L-BFGS: the same closure count as the reference (the strong-Wolfe line search took the same branches), the
-    final loss within 2e-4 of the reference's float64 run, and the weights within 5x the reference float32 runs' distance
+    final loss within 2e-4 of the reference's float64 run, and the weights within 3x the reference float32 runs' distance
     to float64.  "Runs": the fixture also holds the reference's float32 run with the collocation points in another order
-    (the same loss, other rounding), because the line search amplifies rounding and one run is one draw: 5kdv 3.8e-6 /
-    3.8e-6 and GNSS 1.2e-5 / 1.2e-5 of the distance travelled, but Camassa-Holm 4.1e-6 / 1.07e-4 (and 5.9e-4 when the
-    initial weights are perturbed by 1e-7).  Measured here: 5kdv 3.8e-6, GNSS 1.2e-5, CH 3.2e-4 (loss 3.9e-5 off).
+    (the same loss, other rounding) and one from initial weights moved by about one rounding (relative 1e-7), because
+    the line search amplifies rounding and one run is one draw: 5kdv 3.8e-6 / 3.8e-6 / 5.4e-6 and GNSS 1.2e-5 / 1.2e-5 /
+    1.4e-5 of the distance travelled, but Camassa-Holm 4.1e-6 / 1.07e-4 / 5.9e-4.  Measured here: 5kdv 3.8e-6, GNSS
+    1.2e-5, CH 3.2e-4 ... 5.9e-4 depending on the order of the float32 loss sum (loss 3.9e-5 ... 7.6e-5 off).
 
 CPU (not gpu): the classes on the oracle engine with torch's optimizers and with pde_amd.lbfgs.LBFGS on its CPU stand-in
 kernels — this pins the host logic of train().  GPU: the product path (FusedAdam + device L-BFGS, eager and HIP graph;
@@ -68,7 +69,7 @@ def check_adam(case, m, theta):
 def check_end(case, theta, closures, loss):
     th0, t64, t32 = G[case + "_theta0"].astype(np.float64), G[case + "_theta_end64"], G[case + "_theta_end32"]
     travelled = np.linalg.norm(t64 - th0)
-    ref_noise = max(np.linalg.norm(t32 - t64), np.linalg.norm(G[case + "_theta_end32p"] - t64)) / travelled
+    ref_noise = max(np.linalg.norm(t - t64) for t in (t32, G[case + "_theta_end32p"], G[case + "_theta_end32q"])) / travelled
     ours = np.linalg.norm(theta - t64) / travelled
     l64, l0 = float(G[case + "_loss_end64"]), float(G[case + "_loss_start64"])
     print("train golden %s Adam + L-BFGS: ours %.2e, reference float32 runs %.2e of the distance travelled; loss %.6e vs %.6e; "
@@ -76,7 +77,7 @@ def check_end(case, theta, closures, loss):
     assert closures == int(G[case + "_iter_end64"]) == int(G[case + "_iter_end32"]), (case, closures)
     assert l64 < 0.2 * l0                      # the fixture is a run that trains
     assert abs(loss - l64) <= 2e-4 * l64, (case, loss, l64)
-    assert ours <= max(5.0 * ref_noise, 1e-5), (case, ours, ref_noise)
+    assert ours <= max(3.0 * ref_noise, 1e-5), (case, ours, ref_noise)
     return ours, ref_noise
 
 
