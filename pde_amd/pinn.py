@@ -808,8 +808,7 @@ class PhysicsInformedNN:
         last = None
         for _ in range(2):
             graph = torch.cuda.CUDAGraph()
-            gc.collect()
-            was_enabled = gc.isenabled()
+            was_enabled = gc.isenabled()              # (torch.cuda.graph's __enter__ runs a full collection itself)
             gc.disable()
             try:
                 with torch.cuda.graph(graph):
