@@ -91,6 +91,26 @@ def _check(rc, what):
         raise NativeError("%s failed: %s (%d)" % (what, msg, rc))
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL_CTX = _NullCtx()
+
+
+def _on(device):
+    """Context in which `device` is the current HIP device (the library's entry points launch on the current device).
+    Nothing when it already is: torch.cuda.device() costs several microseconds per call, on every launch of a closure."""
+    idx = device.index
+    if idx is None or torch.cuda.current_device() == idx:
+        return _NULL_CTX
+    return torch.cuda.device(device)
+
+
 def _split_xt(x, t):
     """(x, t) -> (x_ptr_tensor, t_ptr_tensor, stride, n).  `t is None` means x is an
     (N,2) row-major [x,t] array (predict's X_star, 7kdv/PI-7kdv3soliton.py:179-184)."""
@@ -120,7 +140,7 @@ def data_loss(out, tgt0, n0, nb, dirichlet, losses=None):
     if losses is None:
         losses = torch.empty(2, dtype=torch.float32, device=out.device)
     assert losses.dtype == torch.float32 and losses.numel() == 2 and losses.is_contiguous() and losses.device == out.device
-    with torch.cuda.device(out.device):
+    with _on(out.device):
         _check(load_library().pinn_data_loss(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
                                              losses.data_ptr(), _cur_stream(out)), "pinn_data_loss")
     return losses
@@ -133,7 +153,7 @@ def data_loss_cotangent(out, tgt0, n0, nb, dirichlet, g0, gb):
     gb = gb.reshape(1).float().contiguous()
     assert tgt0.device == out.device and g0.device == out.device and gb.device == out.device
     gbar = torch.empty_like(out)
-    with torch.cuda.device(out.device):
+    with _on(out.device):
         _check(load_library().pinn_data_loss_cotangent(out.data_ptr(), tgt0.data_ptr(), n0, nb, out.shape[1], int(bool(dirichlet)),
                                                        g0.data_ptr(), gb.data_ptr(), gbar.data_ptr(), _cur_stream(out)),
                "pinn_data_loss_cotangent")
@@ -149,7 +169,7 @@ def closure_sum(terms, n_terms, sums, n_total, ga, gb, grad, accumulate):
         assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.device == grad.device
     assert ga.numel() == P and gb.numel() == P and terms.numel() >= n_terms and 0 <= sums.numel() <= 3
     loss2 = torch.empty(2, dtype=torch.float32, device=grad.device)
-    with torch.cuda.device(grad.device):
+    with _on(grad.device):
         _check(load_library().pinn_closure_sum(terms.data_ptr(), int(n_terms), sums.data_ptr(), sums.numel(), float(n_total),
                                                loss2.data_ptr(), ga.data_ptr(), gb.data_ptr(), grad.data_ptr(), P,
                                                1 if accumulate else 0, _cur_stream(grad)), "pinn_closure_sum")
@@ -182,7 +202,7 @@ class NativeEngine:
             d.coef[i] = float(c)
         d.kernel = kernel
         self._h = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_create(ctypes.byref(d), ctypes.byref(self._h)), "pinn_create")
         self.P = self.lib.pinn_param_count(self._h)
         self.J = self.lib.pinn_jet_count(self._h)
@@ -211,7 +231,7 @@ class NativeEngine:
         self._chk_theta(theta)
         kx, kt, px, pt, stride, n = _split_xt(x, t)
         out = torch.empty((n, self.nout), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_forward(self._h, theta.data_ptr(), px, pt, stride, n, out.data_ptr(),
                                          self._stream()), "pinn_forward")
         return out
@@ -220,7 +240,7 @@ class NativeEngine:
         self._chk_theta(theta)
         kx, kt, px, pt, stride, n = _split_xt(x, t)
         gbar = gbar.reshape(n, self.nout).contiguous().float()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_forward_vjp(self._h, theta.data_ptr(), px, pt, stride, n, gbar.data_ptr(),
                                              grad_accum.data_ptr(), self._stream()), "pinn_forward_vjp")
 
@@ -229,13 +249,13 @@ class NativeEngine:
         self._chk_theta(theta)
         kx, kt, px, pt, stride, n = _split_xt(x, t)
         gbar = gbar.reshape(n, self.nout).contiguous().float()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_forward_vjp_static(self._h, theta.data_ptr(), px, pt, stride, n, gbar.data_ptr(),
                                                     grad_accum.data_ptr(), self._stream()), "pinn_forward_vjp_static")
 
     def reserve(self, n_max):
         """Size the handle's workspace for calls of up to n_max points: no later call allocates."""
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_reserve(self._h, int(n_max)), "pinn_reserve")
 
     # ---- net_f ----
@@ -244,7 +264,7 @@ class NativeEngine:
         kx, kt, px, pt, stride, n = _split_xt(x, t)
         f = torch.empty((n, self.nf), dtype=torch.float32, device=self.device)
         der = torch.empty((n, self.nout, self.J), dtype=torch.float32, device=self.device) if want_derivs else None
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_residual_fwd(self._h, theta.data_ptr(), px, pt, stride, n, f.data_ptr(),
                                               der.data_ptr() if want_derivs else None, self._stream()),
                    "pinn_residual_fwd")
@@ -255,7 +275,7 @@ class NativeEngine:
         derivs = derivs.reshape(-1, self.nout, self.J).contiguous().float()
         n = derivs.shape[0]
         f = torch.empty((n, self.nf), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_residual_from_derivs(self._h, derivs.data_ptr(), n, f.data_ptr(), self._stream()),
                    "pinn_residual_from_derivs")
         return f
@@ -264,7 +284,7 @@ class NativeEngine:
         self._chk_theta(theta)
         kx, kt, px, pt, stride, n = _split_xt(x, t)
         gbar = gbar.reshape(n, self.nf).contiguous().float()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_residual_vjp(self._h, theta.data_ptr(), px, pt, stride, n, gbar.data_ptr(),
                                               grad_accum.data_ptr(), self._stream()), "pinn_residual_vjp")
 
@@ -272,7 +292,7 @@ class NativeEngine:
         """loss_sums_accum[nf] += sum f_c^2 ; grad_accum[P] += scale * d/dtheta sum f^2."""
         self._chk_theta(theta)
         kx, kt, px, pt, stride, n = _split_xt(x, t)
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             _check(self.lib.pinn_loss_grad(self._h, theta.data_ptr(), px, pt, stride, n, float(scale),
                                            loss_sums_accum.data_ptr(), grad_accum.data_ptr(), self._stream()),
                    "pinn_loss_grad")
@@ -300,12 +320,13 @@ class NativeLBFGSKernels:
         # host polls the ticket instead of enqueuing a copy and sleeping on the stream
         self.mirror = torch.zeros(16, dtype=torch.float32, pin_memory=True)
         dptr = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on(self.device):
             rc = self.lib.pinn_host_device_pointer(self.mirror.data_ptr(), ctypes.byref(dptr))
         self.mirror_dev = dptr.value if rc == 0 else None
         self._mirror_f = self.mirror.numpy()
         self._mirror_i = self._mirror_f.view("int32")
         self.ticket = 0
+        self._ws_ptr, self._stats_ptr, self._out_ptr = self.ws.data_ptr(), self.stats.data_ptr(), self.out.data_ptr()
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -318,9 +339,9 @@ class NativeLBFGSKernels:
         self._chk(g); self._chk(d)
         if x is not None:
             self._chk(x); self._chk(x0)
-        with torch.cuda.device(self.device):
-            _check(self.lib.pinn_lbfgs_direction_advance(self.ws.data_ptr(), self.n, self.history, g.data_ptr(), d.data_ptr(),
-                                                         float(t), 1 if first else 0, self.stats.data_ptr(),
+        with _on(self.device):
+            _check(self.lib.pinn_lbfgs_direction_advance(self._ws_ptr, self.n, self.history, g.data_ptr(), d.data_ptr(),
+                                                         float(t), 1 if first else 0, self._stats_ptr,
                                                          x.data_ptr() if x is not None else None,
                                                          x0.data_ptr() if x is not None else None, float(t_next),
                                                          self._stream()), "pinn_lbfgs_direction_advance")
@@ -332,13 +353,14 @@ class NativeLBFGSKernels:
         self._chk(g); self._chk(d)
         if g_copy is not None:
             self._chk(g_copy)
-        loss = loss.detach().reshape(-1).float()
-        assert loss.device == self.device
+        if loss.dtype != torch.float32 or loss.requires_grad:
+            loss = loss.detach().float()
+        assert loss.device == self.device and loss.numel() == 1
         self.ticket = (self.ticket + 1) & 0x3fffffff
-        with torch.cuda.device(self.device):
-            _check(self.lib.pinn_lbfgs_eval_stats_keep(g.data_ptr(), d.data_ptr(), self.n, loss.data_ptr(), self.out.data_ptr(),
+        with _on(self.device):
+            _check(self.lib.pinn_lbfgs_eval_stats_keep(g.data_ptr(), d.data_ptr(), self.n, loss.data_ptr(), self._out_ptr,
                                                        g_copy.data_ptr() if g_copy is not None else None,
-                                                       self.stats.data_ptr(), self.mirror_dev, self.ticket, self._stream()),
+                                                       self._stats_ptr, self.mirror_dev, self.ticket, self._stream()),
                    "pinn_lbfgs_eval_stats_keep")
         return self.out
 
