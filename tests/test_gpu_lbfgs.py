@@ -14,7 +14,9 @@ def _rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
 
 
-@pytest.mark.parametrize("n,hist", [(7851, 5), (30802, 50), (37, 3), (1024, 1), (12737, 150)])
+# history 50: one row per lane, three whole images in LDS; 70: five rows per lane, whole images; 100: one panel per loop;
+# 150: two panels per loop
+@pytest.mark.parametrize("n,hist", [(7851, 5), (30802, 50), (37, 3), (1024, 1), (12737, 150), (2000, 70), (3001, 100)])
 def test_direction_kernel_matches_float64_two_loop(n, hist):
     """A synthetic quadratic-like sequence (g_{k+1} = g_k + A-ish * step) drives both implementations
     through more steps than the history holds (ring wrap) and through rejected pairs (y.s <= 1e-10).
@@ -54,6 +56,77 @@ def test_direction_kernel_matches_float64_two_loop(n, hist):
     assert abs(out[2] - float(g.abs().max())) <= 1e-6 * float(g.abs().max())
 
 
+def test_direction_advance_moves_the_weights_and_eval_stats_keeps_and_mirrors():
+    """pinn_lbfgs_direction_advance with x: the same direction and statistics as without, x0 = x and x = x + t_next d;
+    pinn_lbfgs_eval_stats_keep: the gradient copy, and the pinned-host mirror [stats8 | out4] that `fetch()` polls for
+    equals the device buffers."""
+    from pde_amd._native import NativeLBFGSKernels
+    dev = torch.device("cuda", 0)
+    n, hist = 7851, 6
+    rng = np.random.default_rng(5)
+    ka, kb = NativeLBFGSKernels(n, hist, dev), NativeLBFGSKernels(n, hist, dev)
+    assert ka.mirror_dev is not None, "pinned host memory is not mapped into the device's address space"
+    diag = torch.tensor(rng.uniform(0.5, 4.0, n), dtype=torch.float32, device=dev)
+    g = torch.tensor(rng.standard_normal(n), dtype=torch.float32, device=dev)
+    da, db = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    x = torch.tensor(rng.standard_normal(n), dtype=torch.float32, device=dev)
+    x0 = torch.full((n,), 7.0, device=dev)
+    t = 1.0
+    for it in range(2 * hist + 3):
+        xb = x.clone()
+        sa = ka.direction(g, da, t, it == 0, x=x, x0=x0, t_next=0.5).clone()
+        sb = kb.direction(g, db, t, it == 0).clone()
+        assert torch.equal(da, db) and torch.equal(sa, sb), it
+        assert torch.equal(x0, xb), it
+        want = xb.double() + 0.5 * da.double()
+        assert float((x.double() - want).abs().max()) <= 1.2e-7 * float(want.abs().max()), it
+        t = float(rng.uniform(0.3, 1.0))
+        g = g + diag * (t * da) + 1e-3 * torch.tensor(rng.standard_normal(n), dtype=torch.float32, device=dev)
+        keep = torch.empty_like(g)
+        out = ka.eval_stats(g, da, torch.tensor([0.5 + it], device=dev), keep)
+        stats8, out4 = ka.fetch()
+        torch.cuda.synchronize()
+        assert torch.equal(keep, g)
+        assert out4 == out.cpu().tolist() and stats8 == ka.stats.cpu().tolist(), it
+        assert out4[0] == 0.5 + it
+        assert abs(out4[1] - float(g.double().dot(da.double()))) <= 2e-5 * float(g.double().abs().dot(da.double().abs()))
+
+
+@pytest.mark.parametrize("P,n_terms,nf", [(7851, 2, 1), (30802, 4, 2), (37, 5, 3), (301, 1, 0)])
+def test_closure_sum_matches_the_torch_expressions(P, n_terms, nf):
+    """pinn_closure_sum = what the closure did with a divide and four adds: loss = loss0 + loss_b + loss_f + ... in
+    float32 and this order, loss_f = sum(sums) / N, grad = g_data + g_f (written or accumulated)."""
+    from pde_amd._native import closure_sum
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(P)
+    terms = torch.rand(8, device=dev)
+    sums = torch.rand(nf, device=dev) * 1000.0
+    ga, gb = torch.randn(P, device=dev), torch.randn(P, device=dev)
+    N = 20000.0
+    tc, sc = terms.cpu().numpy(), sums.cpu().numpy()
+    lf = np.float32(0.0)
+    if nf:
+        lf = sc[0]
+        for c in range(1, nf):
+            lf = np.float32(lf + sc[c])
+        lf = np.float32(lf / np.float32(N))
+    want = tc[0]
+    if n_terms > 1:
+        want = np.float32(want + tc[1])
+    want = np.float32(want + lf)
+    for k in range(2, n_terms):
+        want = np.float32(want + tc[k])
+    for accumulate in (False, True):
+        grad = torch.full((P,), 3.0, device=dev)
+        loss2 = closure_sum(terms, n_terms, sums, N, ga, gb, grad, accumulate)
+        torch.cuda.synchronize()
+        assert loss2.cpu().numpy().tolist() == [float(want), float(lf)]
+        ref = ga + gb
+        if accumulate:
+            ref = torch.full((P,), 3.0, device=dev) + ref
+        assert torch.equal(grad, ref)
+
+
 def test_lbfgs_entry_points_reject_bad_arguments():
     from pde_amd._native import load_library
     lib = load_library()
@@ -64,6 +137,10 @@ def test_lbfgs_entry_points_reject_bad_arguments():
     assert small > 2 * 5 * 100 and big > 2 * 51 * 30802 and big < 4 * 51 * 30802
     assert lib.pinn_lbfgs_direction(None, 100, 4, None, None, 1.0, 1, None, None) == -4
     assert lib.pinn_lbfgs_eval_stats(None, None, 100, None, None, None) == -4
+    assert lib.pinn_lbfgs_direction_advance(None, 100, 4, None, None, 1.0, 1, None, None, None, 1.0, None) == -4
+    assert lib.pinn_lbfgs_eval_stats_keep(None, None, 100, None, None, None, None, None, 0, None) == -4
+    assert lib.pinn_closure_sum(None, 2, None, 1, 1.0, None, None, None, None, 10, 0, None) == -4
+    assert lib.pinn_host_device_pointer(None, None) == -4
 
 
 def _burgers_model(impl):
