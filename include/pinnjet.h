@@ -186,6 +186,14 @@ int pinn_loss_grad(pinn_handle *h, const float *theta, const float *x, const flo
  *            [stats8 (8 floats, skipped when stats8 is NULL) | out4 | ticket (int32)], the ticket last and
  *            after a system-scope fence: the host polls that word instead of waiting on the stream
  *            (torch.optim.LBFGS blocks on `float(loss)` and on every scalar it compares).
+ * pinn_lbfgs_poll_advance: HOST work of one line-search evaluation in the usual case, without an interpreter between
+ *            the arrival of the statistics and the next launch: spins (at most max_spins times; returns 2 when they
+ *            run out) until host13[12] == ticket, copies the 12 floats to vals12 and, when allow != 0, the first
+ *            trial point t = lr satisfies both Wolfe conditions against f_prev and stats8's g.d (c1 = 1e-4, c2 = 0.9)
+ *            and none of torch.optim.LBFGS.step's stopping rules fires (direction not descending, max|g| <= tol_g,
+ *            max|d| lr <= tol_x, |f - f_prev| < tol_x), calls pinn_lbfgs_direction_advance(g_keep, t = lr, x, x0, lr)
+ *            and returns 1; returns 0 when the caller has to decide (nothing launched).  host13 is the HOST address
+ *            here.  The same float64 comparisons as pde_amd/lbfgs.py makes, one rounding per operation.
  * pinn_host_device_pointer: the device address of pinned (hipHostMalloc / torch pin_memory) host memory;
  *            PINN_ERR_HIP when the memory is not mapped into the device's address space. */
 int64_t pinn_lbfgs_workspace_floats(int64_t n, int32_t history);
@@ -197,6 +205,10 @@ int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float
                           void *stream);
 int pinn_lbfgs_eval_stats_keep(const float *g, const float *d, int64_t n, const float *loss, float *out4,
                                float *g_copy, const float *stats8, float *host13, int32_t ticket, void *stream);
+int pinn_lbfgs_poll_advance(const float *host13, int32_t ticket, int64_t max_spins, double f_prev, double lr,
+                            double tol_x, double tol_g, int32_t allow, float *workspace, int64_t n, int32_t history,
+                            const float *g_keep, float *d, float *stats8, float *x, float *x0, void *stream,
+                            float *vals12);
 int pinn_host_device_pointer(void *host, void **device);
 
 /* ---- data terms of backward() on the outputs of one net_u batch ------------------------------------------
@@ -221,10 +233,11 @@ int pinn_data_loss_cotangent(const float *out, const float *tgt0, int32_t n0, in
  *   loss2[1] = loss_f = (sums[0] + ... + sums[nf-1]) / n_total        (sums: what pinn_loss_grad accumulated)
  *   loss2[0] = loss   = (((terms[0] + terms[1]) + loss_f) + terms[2]) + ...   (float32, in the reference's order:
  *                       terms = loss0, loss_b, then loss1 / loss_prev / loss_s as present)
- *   grad[i]  = ga[i] + gb[i]   (accumulate != 0: grad[i] += ga[i] + gb[i]; gb may be NULL), i < P
- * n_terms <= 16, nf <= 3. */
-int pinn_closure_sum(const float *terms, int32_t n_terms, const float *sums, int32_t nf, float n_total, float *loss2,
-                     const float *ga, const float *gb, float *grad, int64_t P, int32_t accumulate, void *stream);
+ *   grad[i]  = ga[i] + gb[i]   (flags & 1: grad[i] += ga[i] + gb[i]; gb may be NULL), i < P
+ * flags & 2: gb and sums are set to zero once they have been read - a captured closure keeps ONE collocation buffer
+ * for pinn_loss_grad to accumulate into and never launches a fill for it.  n_terms <= 16, nf <= 3. */
+int pinn_closure_sum(const float *terms, int32_t n_terms, float *sums, int32_t nf, float n_total, float *loss2,
+                     const float *ga, float *gb, float *grad, int64_t P, int32_t flags, void *stream);
 
 /* ---- Adam / AdamW on the device, one launch per step ------------------------------------
  * Replaces torch.optim.Adam / AdamW(weight_decay=1e-2).step() of the reference's Adam phase

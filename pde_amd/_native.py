@@ -41,6 +41,7 @@ SYMBOLS = [
     "pinn_data_loss", "pinn_data_loss_cotangent", "pinn_closure_sum",
     "pinn_lbfgs_workspace_floats", "pinn_lbfgs_direction", "pinn_lbfgs_eval_stats",
     "pinn_lbfgs_direction_advance", "pinn_lbfgs_eval_stats_keep", "pinn_host_device_pointer",
+    "pinn_lbfgs_poll_advance",
 ]
 
 
@@ -74,6 +75,9 @@ def load_library():
     lib.pinn_lbfgs_direction_advance.argtypes = [vp, i64, ctypes.c_int32, vp, vp, f32, ctypes.c_int32, vp, vp, vp, f32, vp]
     lib.pinn_lbfgs_eval_stats_keep.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp, ctypes.c_int32, vp]
     lib.pinn_host_device_pointer.argtypes = [vp, ctypes.POINTER(vp)]
+    f64 = ctypes.c_double
+    lib.pinn_lbfgs_poll_advance.argtypes = [vp, ctypes.c_int32, i64, f64, f64, f64, f64, ctypes.c_int32, vp, i64, ctypes.c_int32,
+                                            vp, vp, vp, vp, vp, vp, vp]
     lib.pinn_adam_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, ctypes.c_double, ctypes.c_double, f32, f32, ctypes.c_int32, vp]
     i32 = ctypes.c_int32
     lib.pinn_data_loss.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
@@ -160,10 +164,10 @@ def data_loss_cotangent(out, tgt0, n0, nb, dirichlet, g0, gb):
     return gbar
 
 
-def closure_sum(terms, n_terms, sums, n_total, ga, gb, grad, accumulate):
+def closure_sum(terms, n_terms, sums, n_total, ga, gb, grad, accumulate, clear=False):
     """The tail of backward() in one launch (include/pinnjet.h, pinn_closure_sum): returns loss2 = [loss, loss_f] with
     loss_f = sum(sums) / n_total and loss = terms[0] + terms[1] + loss_f + terms[2] + ..., and writes (or adds, when
-    `accumulate`) ga + gb into the flat gradient `grad`."""
+    `accumulate`) ga + gb into the flat gradient `grad`.  `clear`: gb and sums are zeroed once read."""
     P = grad.numel()
     for v in (terms, sums, ga, gb, grad):
         assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and v.device == grad.device
@@ -172,7 +176,7 @@ def closure_sum(terms, n_terms, sums, n_total, ga, gb, grad, accumulate):
     with _on(grad.device):
         _check(load_library().pinn_closure_sum(terms.data_ptr(), int(n_terms), sums.data_ptr(), sums.numel(), float(n_total),
                                                loss2.data_ptr(), ga.data_ptr(), gb.data_ptr(), grad.data_ptr(), P,
-                                               1 if accumulate else 0, _cur_stream(grad)), "pinn_closure_sum")
+                                               (1 if accumulate else 0) | (2 if clear else 0), _cur_stream(grad)), "pinn_closure_sum")
     return loss2
 
 
@@ -327,6 +331,8 @@ class NativeLBFGSKernels:
         self._mirror_i = self._mirror_f.view("int32")
         self.ticket = 0
         self._ws_ptr, self._stats_ptr, self._out_ptr = self.ws.data_ptr(), self.stats.data_ptr(), self.out.data_ptr()
+        self._mirror_ptr = self.mirror.data_ptr()
+        self._vals = (ctypes.c_float * 12)()
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -363,6 +369,28 @@ class NativeLBFGSKernels:
                                                        self._stats_ptr, self.mirror_dev, self.ticket, self._stream()),
                    "pinn_lbfgs_eval_stats_keep")
         return self.out
+
+    def poll_advance(self, f_prev, lr, tol_x, tol_g, allow, g_keep, d, x, x0):
+        """Wait for the last eval_stats call's statistics and, in the usual case (first trial point accepted, no stopping
+        rule fires, `allow`), launch the next direction update from C at once (include/pinnjet.h,
+        pinn_lbfgs_poll_advance).  Returns (launched, stats8, out4), or None when the host mirror is not available."""
+        if self.mirror_dev is None:
+            return None
+        self._chk(g_keep); self._chk(d); self._chk(x); self._chk(x0)
+        args = (self._mirror_ptr, self.ticket, 4000000, float(f_prev), float(lr), float(tol_x), float(tol_g),
+                1 if allow else 0, self._ws_ptr, self.n, self.history, g_keep.data_ptr(), d.data_ptr(), self._stats_ptr,
+                x.data_ptr(), x0.data_ptr())
+        with _on(self.device):
+            rc = self.lib.pinn_lbfgs_poll_advance(*args, self._stream(), self._vals)
+            if rc == 2:
+                torch.cuda.current_stream(self.device).synchronize()
+                rc = self.lib.pinn_lbfgs_poll_advance(*args, self._stream(), self._vals)
+                if rc == 2:
+                    raise NativeError("the statistics of a line-search evaluation never reached the host")
+        if rc < 0:
+            _check(rc, "pinn_lbfgs_poll_advance")
+        v = list(self._vals)
+        return rc == 1, v[:8], v[8:]
 
     def fetch(self):
         """(stats8, out4) of the last eval_stats call as Python floats, or None when the host mirror is not available.

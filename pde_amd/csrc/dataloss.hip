@@ -81,15 +81,18 @@ __global__ __launch_bounds__(256) void k_data_cotangent(const float *__restrict_
 // The tail of backward(): `loss = loss0 + loss_b [+ loss1] [+ loss_prev] [+ loss_s] + loss_f; loss.backward()`
 // (7kdv/PI-7kdv3soliton.py:110-111, 7kdv/bc-7kdv3soliton.py:252-253, 7kdv/sw-73.py:142-143) once every term's value and weight gradient exist: the float32 sums in the
 // order the reference adds them, and the two flat gradients (data terms, collocation term) added into `.grad`.
-__global__ __launch_bounds__(256) void k_closure_sum(const float *__restrict__ terms, int n_terms, const float *__restrict__ sums,
+__global__ __launch_bounds__(256) void k_closure_sum(const float *__restrict__ terms, int n_terms, float *__restrict__ sums,
                                                       int nf, float n_total, float *__restrict__ loss2,
-                                                      const float *__restrict__ ga, const float *__restrict__ gb,
-                                                      float *__restrict__ grad, long long P, int accumulate)
+                                                      const float *__restrict__ ga, float *__restrict__ gb,
+                                                      float *__restrict__ grad, long long P, int accumulate, int clear)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < P) {
         float v = ga[i];
-        if (gb) v += gb[i];
+        if (gb) {
+            v += gb[i];
+            if (clear) gb[i] = 0.0f;
+        }
         grad[i] = accumulate ? grad[i] + v : v;
     }
     if (i == 0) {
@@ -98,6 +101,8 @@ __global__ __launch_bounds__(256) void k_closure_sum(const float *__restrict__ t
             lf = sums[0];
             for (int c = 1; c < nf; ++c) lf += sums[c];
             lf = lf / n_total;
+            if (clear)
+                for (int c = 0; c < nf; ++c) sums[c] = 0.0f;
         }
         // the reference's order: loss0 + loss_b + loss_f + (loss1 | loss_prev | loss_s)
         float l = n_terms > 0 ? terms[0] : 0.0f;
@@ -113,14 +118,15 @@ __global__ __launch_bounds__(256) void k_closure_sum(const float *__restrict__ t
 
 extern "C" {
 
-int pinn_closure_sum(const float *terms, int32_t n_terms, const float *sums, int32_t nf, float n_total, float *loss2,
-                     const float *ga, const float *gb, float *grad, int64_t P, int32_t accumulate, void *stream)
+int pinn_closure_sum(const float *terms, int32_t n_terms, float *sums, int32_t nf, float n_total, float *loss2,
+                     const float *ga, float *gb, float *grad, int64_t P, int32_t flags, void *stream)
 {
+    const int accumulate = flags & 1, clear = (flags >> 1) & 1;
     if (!loss2 || !ga || !grad || (n_terms > 0 && !terms) || (nf > 0 && !sums)) return PINN_ERR_NULL;
-    if (n_terms < 0 || n_terms > 16 || nf < 0 || nf > 3 || P <= 0 || !(n_total > 0.0f)) return PINN_ERR_INVALID_DESC;
+    if (n_terms < 0 || n_terms > 16 || nf < 0 || nf > 3 || P <= 0 || !(n_total > 0.0f) || (flags & ~3)) return PINN_ERR_INVALID_DESC;
     if (P > (1LL << 30)) return PINN_ERR_TOO_LARGE;
     hipLaunchKernelGGL(k_closure_sum, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, terms, n_terms, sums,
-                       nf, n_total, loss2, ga, gb, grad, (long long)P, accumulate);
+                       nf, n_total, loss2, ga, gb, grad, (long long)P, accumulate, clear);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) fprintf(stderr, "pinn_closure_sum: %s\n", hipGetErrorString(e));
     return e == hipSuccess ? PINN_OK : PINN_ERR_HIP;

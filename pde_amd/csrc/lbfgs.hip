@@ -656,6 +656,45 @@ int pinn_lbfgs_eval_stats(const float *g, const float *d, int64_t n, const float
     return pinn_lbfgs_eval_stats_keep(g, d, n, loss, out4, nullptr, nullptr, nullptr, 0, stream);
 }
 
+// Host side of one line-search evaluation in the usual case, without the interpreter between the arrival of the
+// statistics and the next launch: wait for the ticket of pinn_lbfgs_eval_stats_keep's host mirror, copy the 12 floats
+// out, and - when the first trial point t = lr satisfies both Wolfe conditions and no stopping rule of
+// torch.optim.LBFGS.step fires - launch the next direction update at once.  The tests are those of pde_amd/lbfgs.py
+// (torch/optim/lbfgs.py: _strong_wolfe's first two tests with c1 = 1e-4, c2 = 0.9, then step()'s), in double precision
+// and one rounding per operation like the interpreter's (volatile temporaries: no fused multiply-add).
+int pinn_lbfgs_poll_advance(const float *host13, int32_t ticket, int64_t max_spins, double f_prev, double lr, double tol_x,
+                            double tol_g, int32_t allow, float *workspace, int64_t n, int32_t history, const float *g_keep,
+                            float *d, float *stats8, float *x, float *x0, void *stream, float *vals12) {
+    if (!host13 || !vals12) return PINN_ERR_NULL;
+    const volatile int *tk = reinterpret_cast<const volatile int *>(host13) + 12;
+    int64_t spins = 0;
+    while (*tk != ticket) {
+        if (++spins > max_spins) return 2;              // not there yet: the caller waits on the stream and calls again
+#if !defined(__HIP_DEVICE_COMPILE__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const volatile float *hv = host13;
+    for (int k = 0; k < 12; ++k) vals12[k] = hv[k];
+    if (!allow) return 0;
+    const double gtd = vals12[0], dmax = vals12[2], fs = vals12[8], gtds = vals12[9], gmaxs = vals12[10];
+    if (gtd > -tol_x) return 0;                         // not a descent direction: the caller undoes the evaluation
+    volatile double a = 1e-4 * lr;
+    a = a * gtd;
+    a = f_prev + a;
+    if (fs > a) return 0;                               // sufficient decrease fails: the caller brackets / zooms
+    volatile double c = -0.9 * gtd;
+    if (!(__builtin_fabs(gtds) <= c)) return 0;         // curvature condition fails
+    if (gmaxs <= tol_g) return 0;                       // step()'s stopping rules
+    volatile double m = dmax * __builtin_fabs(lr);
+    if (m <= tol_x) return 0;
+    volatile double df = fs - f_prev;
+    if (__builtin_fabs(df) < tol_x) return 0;
+    const int rc = pinn_lbfgs_direction_advance(workspace, n, history, g_keep, d, (float)lr, 0, stats8, x, x0, (float)lr, stream);
+    return rc == PINN_OK ? 1 : rc;
+}
+
 int pinn_host_device_pointer(void *host, void **device) {
     if (!host || !device) return PINN_ERR_NULL;
     *device = nullptr;

@@ -289,13 +289,18 @@ class LBFGS(torch.optim.Optimizer):
         g = g.clone()
         t = st.get("t", lr)
         n_iter = 0
+        launched = False                    # the direction of the coming iteration is already on its way (poll_advance)
+        poll_advance = getattr(self._k, "poll_advance", None) if self.speculate else None
         while n_iter < max_iter:
             n_iter += 1
             st["n_iter"] += 1
             first = st["n_iter"] == 1
             spec = x0 = None
             speculating = wolfe and not first and self.speculate
-            if speculating:
+            if launched:
+                launched = False
+                dstats = self._k.stats
+            elif speculating:
                 if self._x0 is None:
                     self._x0 = torch.empty_like(self._x)
                 dstats = self._k.direction(g, self._d, t, first, x=self._x, x0=self._x0, t_next=lr)
@@ -311,7 +316,23 @@ class LBFGS(torch.optim.Optimizer):
                 # closure's owner roll back its own side effects (PhysicsInformedNN: the iteration counter).
                 x0 = self._x0
                 gs, ev = self._evaluate_async(closure, x0, lr, moved=True)
-                (gtd, gsum, dmax, _gm, _cnt, _hd, _, _), (fs, gtds, gmaxs, _) = self._read2(dstats, ev)
+                got = None
+                if poll_advance is not None:
+                    # the wait, the usual decision (first trial point accepted, no stopping rule fires) and the next
+                    # direction's launch happen in C, back to back: the interpreter is not between the statistics'
+                    # arrival and the GPU's next work.  Same tests, same arithmetic as below.
+                    got = poll_advance(f, lr, tol_x, tol_g, n_iter != max_iter and evals + 1 < max_eval, gs, self._d,
+                                       self._x, self._x0)
+                if got is not None:
+                    self.host_syncs += 1
+                    launched, (gtd, gsum, dmax, _gm, _cnt, _hd, _, _), (fs, gtds, gmaxs, _) = got
+                    if launched:
+                        t, f, g, gmax = lr, fs, gs, gmaxs
+                        evals += 1
+                        st["func_evals"] += 1
+                        continue
+                else:
+                    (gtd, gsum, dmax, _gm, _cnt, _hd, _, _), (fs, gtds, gmaxs, _) = self._read2(dstats, ev)
                 spec = True
             else:
                 gtd, gsum, dmax, _gm, _cnt, _hd, _, _ = self._read(dstats)

@@ -345,8 +345,19 @@ class PhysicsInformedNN:
         if one is None or one.device != theta.device:
             one = self._one = torch.ones((), dtype=torch.float32, device=theta.device)
 
+        # (the derivative regulariser's share of loss_f is read from the sums again for the log line: not with nf = 3)
+        persist = assign_grad and nf != 3
+
         def collocation():
-            buf = torch.zeros(P + nf, dtype=torch.float32, device=theta.device)
+            if persist:
+                # the captured closure: ONE buffer for the collocation pass to accumulate into, zeroed here once and by
+                # pinn_closure_sum after every use (flag `clear`) - no fill launch in front of the kernel
+                buf = getattr(self, "_colloc_buf", None)
+                if buf is None or buf.numel() != P + nf + 3 or buf.device != theta.device:
+                    buf = self._colloc_buf = torch.zeros(P + nf + 3, dtype=torch.float32, device=theta.device)
+                buf = buf[:P + nf]
+            else:
+                buf = torch.zeros(P + nf, dtype=torch.float32, device=theta.device)
             self.engine_f.loss_grad(theta, self.xf, self.tf, 1.0 / N, buf[P:], buf[:P])
             self.engine_f.last_sums = buf[P:]
             return buf
@@ -402,7 +413,7 @@ class PhysicsInformedNN:
         flat = dnn.flat_grad_view() if theta.is_cuda else None
         if flat is not None:
             from ._native import closure_sum
-            loss2 = closure_sum(terms, n_terms, buf[P:], N, g, buf[:P], flat, accumulate=not assign_grad)
+            loss2 = closure_sum(terms, n_terms, buf[P:], N, g, buf[:P], flat, accumulate=not assign_grad, clear=persist)
             loss, loss_f = loss2[0], loss2[1]
         else:
             if assign_grad:
@@ -772,10 +783,18 @@ class PhysicsInformedNN:
             torch.cuda.synchronize(self.device)
             opt.zero_grad(set_to_none=True)
 
+            # the direct closure writes the flat gradient in its last launch: no zeroing launches in front of the kernels
+            assign = (self._fused_adam and self.group is None and self.closure_impl == "direct"
+                      and not getattr(self, "earliest_solutions", None) and self.dnn.flat_grad_view() is not None
+                      and self.dnn.flat_grad_view().data_ptr() == opt.flat_grad().data_ptr())
+
             def body():
-                if self._fused_adam:
-                    opt.flat_grad().zero_()             # the flat gradient is a static buffer: cleared inside the graph
-                terms = self._loss_terms(overlap=True)
+                if assign:
+                    terms = self._loss_terms_direct(overlap=True, assign_grad=True)
+                else:
+                    if self._fused_adam:
+                        opt.flat_grad().zero_()         # the flat gradient is a static buffer: cleared inside the graph
+                    terms = self._loss_terms(overlap=True)
                 opt.step()
                 return terms
             graph, terms = self._capture(body)

@@ -116,15 +116,20 @@ def test_closure_sum_matches_the_torch_expressions(P, n_terms, nf):
     want = np.float32(want + lf)
     for k in range(2, n_terms):
         want = np.float32(want + tc[k])
-    for accumulate in (False, True):
+    for accumulate, clear in ((False, False), (True, False), (False, True)):
         grad = torch.full((P,), 3.0, device=dev)
-        loss2 = closure_sum(terms, n_terms, sums, N, ga, gb, grad, accumulate)
+        gb_in, sums_in = gb.clone(), sums.clone()
+        loss2 = closure_sum(terms, n_terms, sums_in, N, ga, gb_in, grad, accumulate, clear)
         torch.cuda.synchronize()
         assert loss2.cpu().numpy().tolist() == [float(want), float(lf)]
         ref = ga + gb
         if accumulate:
             ref = torch.full((P,), 3.0, device=dev) + ref
         assert torch.equal(grad, ref)
+        if clear:                   # (the captured closure's one collocation buffer is left zeroed for the next replay)
+            assert not gb_in.any() and not sums_in.any()
+        else:
+            assert torch.equal(gb_in, gb) and torch.equal(sums_in, sums)
 
 
 def test_lbfgs_entry_points_reject_bad_arguments():
