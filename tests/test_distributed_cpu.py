@@ -1,4 +1,4 @@
-"""CPU, world_size 2 on gloo: sharding of the collocation points + the one
+"""CPU, world_size 2 (and 3, 4) on gloo: sharding of the collocation points + the one
 all-reduce per closure give every rank the same loss/gradient as a single
 process on all points.  Compute comes from the TEST-ONLY oracle
 engine; this tests the host logic of pde_amd/pinn.py and nn.py."""
@@ -86,20 +86,22 @@ def _worker(rank, world, port, name, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", sorted(CASES))
-def test_two_rank_sharding_matches_single_process(name):
-    world = 2
+@pytest.mark.parametrize("name,world", [(n, 2) for n in sorted(CASES)] + [("kdv7_bc_xavier", 4), ("kdv5_xavier", 3)])
+def test_sharding_matches_single_process(name, world):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), name, out), nprocs=world, join=True)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     n = len(g["x"])
-    assert out[0][0] + out[1][0] == n and abs(out[0][0] - out[1][0]) <= 1
-    # identical on both ranks (all-reduce result), and equal to the reference's full backward()
-    assert out[0][1] == out[1][1]
-    assert np.array_equal(out[0][2], out[1][2])
+    shards = [out[r][0] for r in range(world)]
+    assert sum(shards) == n and max(shards) - min(shards) <= 1
+    # identical on every rank (all-reduce result), and equal to the reference's full backward()
+    for r in range(1, world):
+        assert out[0][1] == out[r][1]
+        assert np.array_equal(out[0][2], out[r][2])
     assert abs(out[0][1] - g["loss_full64"]) <= 1e-5 * g["loss_full64"]
     err = np.linalg.norm(out[0][2].astype(np.float64) - g["grad_full64"]) / np.linalg.norm(g["grad_full64"])
     assert err < 1e-5
-    assert out["drift_0"] == "detected" and out["drift_1"] == "detected"
-    assert out["lbfgs_iter_0"] == out["lbfgs_iter_1"] > 3
+    for r in range(world):
+        assert out["drift_%d" % r] == "detected"
+        assert out["lbfgs_iter_%d" % r] == out["lbfgs_iter_0"] > 3
