@@ -65,7 +65,8 @@ def test_direction_advance_moves_the_weights_and_eval_stats_keeps_and_mirrors():
     n, hist = 7851, 6
     rng = np.random.default_rng(5)
     ka, kb = NativeLBFGSKernels(n, hist, dev), NativeLBFGSKernels(n, hist, dev)
-    assert ka.mirror_dev is not None, "pinned host memory is not mapped into the device's address space"
+    if ka.mirror_dev is None:       # (the library then reads the statistics with a copy + stream wait; never seen on this pool)
+        pytest.skip("pinned host memory is not mapped into the device's address space on this box")
     diag = torch.tensor(rng.uniform(0.5, 4.0, n), dtype=torch.float32, device=dev)
     g = torch.tensor(rng.standard_normal(n), dtype=torch.float32, device=dev)
     da, db = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
