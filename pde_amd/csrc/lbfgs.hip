@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/pinnjet.h"
 
 namespace {
@@ -257,14 +259,15 @@ __global__ __launch_bounds__(LB_BLOCK) void k_scalars(char *__restrict__ ws, int
 
     // stage `nl` lines of a Gram matrix G (columns m when `cols`, rows otherwise) starting at logical index m0:
     // dst[(m - m0) * ldc + k] = G[k][m] (cols) or G[m][k] (rows), k < count, logical indices; threads t0, t0+nt, ...
-    // of the workgroup take part; eight loads in flight per thread
+    // of the workgroup take part; sixteen loads in flight per thread
     auto stage = [&](const double *G, double *dst, int m0, int nl, bool cols, int t0, int nt) {
+        constexpr int U = 16;
         const int tot = nl * count;
-        for (int base = tid - t0; base < tot; base += nt * 8) {
-            double v[8];
-            int di[8];
+        for (int base = tid - t0; base < tot; base += nt * U) {
+            double v[U];
+            int di[U];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const int idx = base + nt * u;
                 const bool ok = idx < tot;
                 const int mm = ok ? idx / count : 0, k = ok ? idx - mm * count : 0;
@@ -273,12 +276,11 @@ __global__ __launch_bounds__(LB_BLOCK) void k_scalars(char *__restrict__ ws, int
                 v[u] = cols ? G[int64_t(jk) * slots + jm] : G[int64_t(jm) * slots + jk];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < U; ++u)
                 if (di[u] >= 0) dst[di[u]] = v[u];
         }
     };
 
-    const int nk = (count + 63) >> 6;                   // rows per lane actually in use (wave-uniform)
     double acc[NK], alr[NK], own_ro[NK], own_b[NK];
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
@@ -288,38 +290,86 @@ __global__ __launch_bounds__(LB_BLOCK) void k_scalars(char *__restrict__ ws, int
         own_ro[i] = k < count ? rok[k] : 0.0;
         own_b[i] = k < count ? bk[k] : 0.0;
     }
-    // one run of steps of the first loop on wave 0:  al_m = ro_m ( -s_m.g - sum_{m'>m} al_m' s_m.y_m' ),  m = mhi-1 .. mlo
-    auto loop1 = [&](const double *pan, int mlo, int mhi) {
-        for (int m = mhi - 1; m >= mlo; --m) {
-            const int ol = __builtin_amdgcn_readfirstlane(m & 63), oi = __builtin_amdgcn_readfirstlane(m >> 6);
-            double mine = 0.0;
+    // The sequential loops on wave 0, in blocks of 64 steps whose owner row index OI = m >> 6 is a compile-time constant:
+    // no select over the rows a lane owns, only the rows that can take part are touched (first loop: rows i <= OI,
+    // second loop: rows i >= OI), and the panel values of the next step are loaded before the current step's arithmetic
+    // (their addresses do not depend on the recursion; left to itself every step waited for its own LDS reads).
+    //   first loop:  al_m = ro_m ( -s_m.g - sum_{m'>m} al_m' s_m.y_m' ),  m descending
+    auto loop1_blk = [&](auto oic, const double *pan, int mlo, int lo, int hi) {
+        constexpr int OI = decltype(oic)::value;
+        if constexpr (OI < NK) {
+            double cur[OI + 1], nxt[OI + 1];
+            auto fetch = [&](int m, double *dst) {
 #pragma unroll
-            for (int i = 0; i < NK; ++i) mine = (i == oi) ? own_ro[i] * (-own_b[i] - acc[i]) : mine;
-            const double alm = readlane_f64(mine, ol);
+                for (int i = 0; i <= OI; ++i) {
+                    const int k = lane + 64 * i;
+                    dst[i] = pan[(m - mlo) * ldc + (k < count ? k : count - 1)];
+                }
+            };
+            fetch(hi - 1, cur);
+            for (int m = hi - 1; m >= lo; --m) {
+                const int ol = __builtin_amdgcn_readfirstlane(m & 63);
+                fetch(m > lo ? m - 1 : m, nxt);
+                const double alm = readlane_f64(own_ro[OI] * (-own_b[OI] - acc[OI]), ol);
+                if (lane == ol) alr[OI] = alm;
 #pragma unroll
-            for (int i = 0; i < NK; ++i) {
-                const int k = lane + 64 * i;
-                if (i == oi && lane == ol) alr[i] = alm;
-                if (i < nk && k < m) acc[i] = fma(alm, pan[(m - mlo) * ldc + k], acc[i]);
+                for (int i = 0; i < OI; ++i) acc[i] = fma(alm, cur[i], acc[i]);
+                if (lane < ol) acc[OI] = fma(alm, cur[OI], acc[OI]);
+#pragma unroll
+                for (int i = 0; i <= OI; ++i) cur[i] = nxt[i];
             }
         }
     };
+    auto loop1 = [&](const double *pan, int mlo, int mhi) {
+        auto blk = [&](auto oic) {
+            constexpr int OI = decltype(oic)::value;
+            const int lo = mlo > 64 * OI ? mlo : 64 * OI, hi = mhi < 64 * (OI + 1) ? mhi : 64 * (OI + 1);
+            if (lo < hi) loop1_blk(oic, pan, mlo, lo, hi);
+        };
+        blk(std::integral_constant<int, 4>{});
+        blk(std::integral_constant<int, 3>{});
+        blk(std::integral_constant<int, 2>{});
+        blk(std::integral_constant<int, 1>{});
+        blk(std::integral_constant<int, 0>{});
+    };
     double own_A[NK], ccr[NK];
-    //   cc_m = al_m - ro_m (A_m + sum_{m'<m} cc_m' s_m'.y_m),  m = mlo .. mhi-1
-    auto loop2 = [&](const double *pan, int mlo, int mhi) {
-        for (int m = mlo; m < mhi; ++m) {
-            const int ol = __builtin_amdgcn_readfirstlane(m & 63), oi = __builtin_amdgcn_readfirstlane(m >> 6);
-            double mine = 0.0;
+    //   second loop:  cc_m = al_m - ro_m (A_m + sum_{m'<m} cc_m' s_m'.y_m),  m ascending
+    auto loop2_blk = [&](auto oic, const double *pan, int mlo, int lo, int hi) {
+        constexpr int OI = decltype(oic)::value;
+        if constexpr (OI < NK) {
+            double cur[NK - OI], nxt[NK - OI];
+            auto fetch = [&](int m, double *dst) {
 #pragma unroll
-            for (int i = 0; i < NK; ++i) mine = (i == oi) ? alr[i] - own_ro[i] * (own_A[i] + acc[i]) : mine;
-            const double ccm = readlane_f64(mine, ol);
+                for (int i = OI; i < NK; ++i) {
+                    const int k = lane + 64 * i;
+                    dst[i - OI] = pan[(m - mlo) * ldc + (k < count ? k : count - 1)];
+                }
+            };
+            fetch(lo, cur);
+            for (int m = lo; m < hi; ++m) {
+                const int ol = __builtin_amdgcn_readfirstlane(m & 63);
+                fetch(m + 1 < hi ? m + 1 : m, nxt);
+                const double ccm = readlane_f64(alr[OI] - own_ro[OI] * (own_A[OI] + acc[OI]), ol);
+                if (lane == ol) ccr[OI] = ccm;
+                if (lane > ol) acc[OI] = fma(ccm, cur[0], acc[OI]);
 #pragma unroll
-            for (int i = 0; i < NK; ++i) {
-                const int k = lane + 64 * i;
-                if (i == oi && lane == ol) ccr[i] = ccm;
-                if (i < nk && k > m && k < count) acc[i] = fma(ccm, pan[(m - mlo) * ldc + k], acc[i]);
+                for (int i = OI + 1; i < NK; ++i) acc[i] = fma(ccm, cur[i - OI], acc[i]);   // (rows k >= count: never read)
+#pragma unroll
+                for (int i = 0; i < NK - OI; ++i) cur[i] = nxt[i];
             }
         }
+    };
+    auto loop2 = [&](const double *pan, int mlo, int mhi) {
+        auto blk = [&](auto oic) {
+            constexpr int OI = decltype(oic)::value;
+            const int lo = mlo > 64 * OI ? mlo : 64 * OI, hi = mhi < 64 * (OI + 1) ? mhi : 64 * (OI + 1);
+            if (lo < hi) loop2_blk(oic, pan, mlo, lo, hi);
+        };
+        blk(std::integral_constant<int, 0>{});
+        blk(std::integral_constant<int, 1>{});
+        blk(std::integral_constant<int, 2>{});
+        blk(std::integral_constant<int, 3>{});
+        blk(std::integral_constant<int, 4>{});
     };
     auto publish_al = [&]() {
         if (wave == 0) {
@@ -340,12 +390,12 @@ __global__ __launch_bounds__(LB_BLOCK) void k_scalars(char *__restrict__ ws, int
             if (yy) {
                 for (int m = pt; m < count; m += 4) a = fma(al[m], yy[k * ldc + m], a);
             } else {
-                for (int m0 = pt; m0 < count; m0 += 32) {
-                    double v[8];
+                for (int m0 = pt; m0 < count; m0 += 64) {
+                    double v[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = YY[int64_t(j) * slots + sord[m0 + 4 * u < count ? m0 + 4 * u : 0]];
+                    for (int u = 0; u < 16; ++u) v[u] = YY[int64_t(j) * slots + sord[m0 + 4 * u < count ? m0 + 4 * u : 0]];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
+                    for (int u = 0; u < 16; ++u)
                         if (m0 + 4 * u < count) a = fma(al[m0 + 4 * u], v[u], a);
                 }
             }
@@ -380,23 +430,39 @@ __global__ __launch_bounds__(LB_BLOCK) void k_scalars(char *__restrict__ ws, int
         __syncthreads();
         fold_A(yyl);
         if (wave == 0) loop2(pan2, 0, count);
-    } else {
-        for (int mhi = count; mhi > 0; mhi -= pcols) {
-            const int mlo = mhi > pcols ? mhi - pcols : 0;
-            __syncthreads();                                // the previous panel is no longer read
-            stage(SY, panel, mlo, mhi - mlo, true, 0, LB_BLOCK);
+    } else if (count > 0) {
+        // Larger histories: half panels, one read by wave 0 while the other three waves stage the next one (the last
+        // panel of the first loop is overlapped with the first panel of the second loop: rows 0 .. pc-1).
+        const int pc = pcols >> 1;
+        double *pb[2] = {panel, panel + pc * ldc};
+        const int np = (count + pc - 1) / pc;
+        stage(SY, pb[0], count > pc ? count - pc : 0, count > pc ? pc : count, true, 0, LB_BLOCK);
+        __syncthreads();
+        for (int i = 0; i < np; ++i) {
+            const int mhi = count - i * pc, mlo = mhi > pc ? mhi - pc : 0;
+            if (wave == 0) {
+                loop1(pb[i & 1], mlo, mhi);
+            } else if (i + 1 < np) {
+                const int nlo = mlo > pc ? mlo - pc : 0;
+                stage(SY, pb[(i + 1) & 1], nlo, mlo - nlo, true, 64, LB_BLOCK - 64);
+            } else {
+                stage(SY, pb[(i + 1) & 1], 0, count > pc ? pc : count, false, 64, LB_BLOCK - 64);
+            }
             __syncthreads();
-            if (wave == 0) loop1(panel, mlo, mhi);
         }
         publish_al();
         __syncthreads();
         fold_A(nullptr);
-        for (int mlo = 0; mlo < count; mlo += pcols) {
-            const int mhi = mlo + pcols < count ? mlo + pcols : count;
+        for (int i = 0; i < np; ++i) {
+            const int mlo = i * pc, mhi = mlo + pc < count ? mlo + pc : count;
+            const int cur = (np + i) & 1;
+            if (wave == 0) {
+                loop2(pb[cur], mlo, mhi);
+            } else if (i + 1 < np) {
+                const int nhi = mhi + pc < count ? mhi + pc : count;
+                stage(SY, pb[cur ^ 1], mhi, nhi - mhi, false, 64, LB_BLOCK - 64);
+            }
             __syncthreads();
-            stage(SY, panel, mlo, mhi - mlo, false, 0, LB_BLOCK);
-            __syncthreads();
-            if (wave == 0) loop2(panel, mlo, mhi);
         }
     }
     if (wave == 0) {

@@ -23,6 +23,8 @@ CASES = {
     "kdv5": dict(family="kdv5_1soliton", layers=[2, 50, 50, 50, 50, 1], lb=[-10.0, -2.0], ub=[10.0, 2.0]),
     "kdv7": dict(family="kdv7_3soliton", layers=[2, 50, 50, 50, 50, 1], lb=[-15.0, -0.5], ub=[15.0, 0.5]),
     "gnss": dict(family="gnss", layers=[2, 100, 100, 100, 100, 2], lb=[-5.0, -2.0], ub=[5.0, 0.0]),
+    # CH/PI-CH-1soliton.py:145-154: lr 0.5, history 150 (the direction kernels' panel path)
+    "ch": dict(family="camassa_holm", layers=[2, 50, 50, 50, 50, 1], lb=[-15.0, -1.0], ub=[15.0, 1.0]),
 }
 
 
