@@ -134,14 +134,35 @@ __global__ __launch_bounds__(LB_BLOCK) void k_dots(char *__restrict__ ws, int n,
     const float *Sj = at<float>(ws, L.S) + int64_t(slot) * L.np;
     const float *Yj = at<float>(ws, L.Y) + int64_t(slot) * L.np;
     double a[LB_NDOT] = {0, 0, 0, 0, 0};
+    // every load of the thread's LB_EPT elements is issued before the first use (indices past the end are clamped and
+    // their products dropped): one memory round trip per workgroup instead of one to three per element
+    float gv[LB_EPT], pv[LB_EPT], dv[LB_EPT], sv[LB_EPT], yv[LB_EPT];
+    const bool is_cand = slot == cand;                   // uniform over the workgroup
+#pragma unroll
+    for (int e = 0; e < LB_EPT; ++e) {
+        const int i = chunk * LB_CHUNK + e * LB_BLOCK + threadIdx.x;
+        const int ii = i < n ? i : n - 1;
+        gv[e] = g[ii];
+        pv[e] = prev_g[ii];
+        dv[e] = d[ii];
+    }
+    if (!is_cand) {
+#pragma unroll
+        for (int e = 0; e < LB_EPT; ++e) {
+            const int i = chunk * LB_CHUNK + e * LB_BLOCK + threadIdx.x;
+            const int ii = i < n ? i : n - 1;
+            sv[e] = Sj[ii];
+            yv[e] = Yj[ii];
+        }
+    }
 #pragma unroll
     for (int e = 0; e < LB_EPT; ++e) {
         const int i = chunk * LB_CHUNK + e * LB_BLOCK + threadIdx.x;
         if (i < n) {
-            const float gi = g[i];
-            const float yc = gi - prev_g[i], sc = d[i] * t;
-            const float sj = slot == cand ? sc : Sj[i];
-            const float yj = slot == cand ? yc : Yj[i];
+            const float gi = gv[e];
+            const float yc = gi - pv[e], sc = dv[e] * t;
+            const float sj = is_cand ? sc : sv[e];
+            const float yj = is_cand ? yc : yv[e];
             a[0] = fma((double)sj, (double)gi, a[0]);    // s_j.g
             a[1] = fma((double)yj, (double)gi, a[1]);    // y_j.g
             a[2] = fma((double)sj, (double)yc, a[2]);    // s_j.y_c
@@ -522,35 +543,42 @@ __global__ __launch_bounds__(LB_BLOCK) void k_combine(char *__restrict__ ws, int
     double st[4] = {0, 0, 0, 0};    // g.d, sum|g|, max|d|, max|g|
     const int wv = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    double acc = 0.0;
-    if (i < n) {
-        int k = wv;
-        for (; k + 12 < stored; k += 16) {              // 8 independent loads in flight
-            float yv[4], sv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t row = int64_t(sord[k + 4 * u]) * L.np + i;
-                yv[u] = Y[row];
-                sv[u] = S[row];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = fma(cY[k + 4 * u], (double)yv[u], acc);
-                acc = fma(cS[k + 4 * u], (double)sv[u], acc);
-            }
+    const int ic = i < n ? i : n - 1;
+    // wave 0's own operands are requested before the history sums (nothing of theirs is needed until after the barrier)
+    float gi = 0.f, pgi = 0.f, dold = 0.f, xi = 0.f;
+    if (wv == 0) {
+        gi = g[ic];
+        if (!first) {
+            pgi = prev_g[ic];
+            dold = d[ic];
         }
-        for (; k < stored; k += 4) {
-            const int64_t row = int64_t(sord[k]) * L.np + i;
-            acc = fma(cY[k], (double)Y[row], acc);
-            acc = fma(cS[k], (double)S[row], acc);
+        if (x) xi = x[ic];
+    }
+    double acc = 0.0;
+    // the wave's rows k = wv, wv+4, ...: sixteen rows (32 loads) in flight per pass - one pass up to history 64
+    for (int kb = wv; kb < stored; kb += 64) {
+        float yv[16], sv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = kb + 4 * u;
+            const int64_t row = int64_t(sord[k < stored ? k : kb]) * L.np + ic;
+            yv[u] = Y[row];
+            sv[u] = S[row];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = kb + 4 * u;
+            if (k < stored) {
+                acc = fma(cY[k], (double)yv[u], acc);
+                acc = fma(cS[k], (double)sv[u], acc);
+            }
         }
     }
     if (wv > 0) psum[wv - 1][threadIdx.x & 63] = acc;
     __syncthreads();
     if (wv == 0 && i < n) {
-        const float gi = g[i];
-        const float yc = first ? 0.f : gi - prev_g[i];
-        const float sc = first ? 0.f : d[i] * t;
+        const float yc = first ? 0.f : gi - pgi;
+        const float sc = first ? 0.f : dold * t;
         const int e = threadIdx.x;
         acc = cG * (double)gi + ((acc + psum[0][e]) + (psum[1][e] + psum[2][e]));
         if (newest >= 0) {
@@ -563,7 +591,6 @@ __global__ __launch_bounds__(LB_BLOCK) void k_combine(char *__restrict__ ws, int
         d[i] = di;
         prev_g[i] = gi;
         if (x) {                                        // the line search's first trial point, x0 kept for the others
-            const float xi = x[i];
             x0[i] = xi;
             x[i] = xi + t_next * di;
         }
@@ -616,12 +643,26 @@ __global__ __launch_bounds__(1024) void k_lbfgs_eval_stats(const float *__restri
                                                            float *host13, int ticket) {
     __shared__ double red[16 * 3];
     double s0 = 0, s1 = 0, m = 0;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const float gi = g[i];
-        if (g_copy) g_copy[i] = gi;
-        s0 = fma((double)gi, (double)d[i], s0);
-        s1 += fabs((double)gi);
-        m = fmax(m, fabs((double)gi));
+    // eight elements per thread and pass, all loads first (left as a plain loop every element waited for its own two loads)
+    for (int base = threadIdx.x; base < n; base += 1024 * 8) {
+        float gv[8], dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 1024 * u, ii = i < n ? i : n - 1;
+            gv[u] = g[ii];
+            dv[u] = d[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 1024 * u;
+            if (i < n) {
+                const float gi = gv[u];
+                if (g_copy) g_copy[i] = gi;
+                s0 = fma((double)gi, (double)dv[u], s0);
+                s1 += fabs((double)gi);
+                m = fmax(m, fabs((double)gi));
+            }
+        }
     }
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
