@@ -34,14 +34,39 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_data_loss(const float *__restr
     __shared__ double part[2][LOSS_THREADS / 64];
     double s0 = 0.0, sb = 0.0;
     const int e0 = n0 * nout;
-    for (int i = threadIdx.x; i < e0; i += LOSS_THREADS) {
-        const float r = out[i] - tgt0[i];
-        s0 += (double)r * r;
+    // eight elements per thread and pass, all loads issued before the first use (the bc classes' loss1 batch is 77 312
+    // rows: as a plain loop each of its 75 passes waited for its own two loads); same summation order as the plain loop
+    constexpr int U = 8;
+    for (int base = threadIdx.x; base < e0; base += LOSS_THREADS * U) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + LOSS_THREADS * u, ii = i < e0 ? i : e0 - 1;
+            a[u] = out[ii];
+            b[u] = tgt0[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + LOSS_THREADS * u < e0) {
+                const float r = a[u] - b[u];
+                s0 += (double)r * r;
+            }
     }
     const int eb = (dirichlet ? 2 * nb : nb) * nout;
-    for (int i = threadIdx.x; i < eb; i += LOSS_THREADS) {
-        const float r = dirichlet ? out[e0 + i] : out[e0 + i] - out[e0 + nb * nout + i];
-        sb += (double)r * r;
+    for (int base = threadIdx.x; base < eb; base += LOSS_THREADS * U) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + LOSS_THREADS * u, ii = i < eb ? i : eb - 1;
+            a[u] = out[e0 + ii];
+            b[u] = dirichlet ? 0.0f : out[e0 + nb * nout + ii];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (base + LOSS_THREADS * u < eb) {
+                const float r = a[u] - b[u];
+                sb += (double)r * r;
+            }
     }
     s0 = wave_sum_d(s0);
     sb = wave_sum_d(sb);
