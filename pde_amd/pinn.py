@@ -76,9 +76,9 @@ class PhysicsInformedNN:
     default_device = None            # None -> current CUDA device
     kernel = KERNEL_AUTO
     use_hip_graph = False            # train(): replay the Adam phase / the L-BFGS closure from a captured HIP graph
-    # eager backward(): the collocation kernel on a second stream beside the data-term chain.  None = automatic:
-    # only when that kernel is long enough to pay for the extra host work of two streams (measured at 20 000
-    # points: GNSS width 100 +20 % closures/s, width-50 nets -20 %: their eager closures are host-bound)
+    # eager backward(): the collocation kernel on a second stream beside the data-term chain.  None = automatic: on,
+    # on a GPU (round 3, at 20 000 points: Burgers +11 %, 5kdv / 7kdv +7 % closures/s, GNSS width 100 +30 %; in round 2 the
+    # host work of two streams cost the width-50 nets 20 % - their eager closures were host-bound then)
     overlap_streams = None
     closure_impl = "direct"          # backward(): "direct" (no autograd graph, see _loss_terms_direct) or "autograd"
     hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
@@ -663,7 +663,7 @@ class PhysicsInformedNN:
         returns the 0-dim loss with `.grad` accumulated on dnn.parameters()."""
         ov = self.overlap_streams
         if ov is None:
-            ov = self.xf.shape[0] * self.engine_f.P >= 4e8
+            ov = True
         terms = self._loss_terms(overlap=ov)
         self._log_terms(terms)
         self.iter += 1
