@@ -303,7 +303,7 @@ class NativeEngine:
 
 
 class NativeLBFGSKernels:
-    """Device side of pde_amd.lbfgs.LBFGS: the history ring and the two launches of
+    """Device side of pde_amd.lbfgs.LBFGS: the history ring, the statistics buffers (and their pinned-host mirror) and
     include/pinnjet.h's pinn_lbfgs_* entry points, on torch's current stream."""
 
     def __init__(self, n, history, device):

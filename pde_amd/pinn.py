@@ -83,7 +83,7 @@ class PhysicsInformedNN:
     closure_impl = "direct"          # backward(): "direct" (no autograd graph, see _loss_terms_direct) or "autograd"
     hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
     adam_impl = "fused"              # "fused": pde_amd.optim.FusedAdam (one launch per step); "torch": torch.optim.Adam/AdamW
-    lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (one launch per direction); "torch": torch.optim.LBFGS
+    lbfgs_impl = "device"            # "device": pde_amd.lbfgs.LBFGS (three launches per direction, csrc/lbfgs.hip); "torch": torch.optim.LBFGS
     shard_loss1_min_rows = 4096      # sharded runs: a bc class's loss1 grid of at least this many rows is sharded over the ranks
     lbfgs_kernels_factory = None     # test hook: callable(n, history) -> stand-in for the L-BFGS launches
     engine_factory = None            # test hook: callable(equation|None, layers, lb, ub, device) -> engine
