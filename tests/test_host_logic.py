@@ -233,3 +233,51 @@ def test_library_exports_every_declared_symbol():
     h = ctypes.c_void_p()
     assert lib.pinn_create(ctypes.byref(d), ctypes.byref(h)) == -1
     assert lib.pinn_create(None, ctypes.byref(h)) == -4
+
+
+def test_poll_advance_decides_like_the_python_line_search():
+    """pinn_lbfgs_poll_advance is host code: its decision (launch the next direction, or hand the numbers back) against the
+    conditions of pde_amd/lbfgs.py on random and borderline inputs, without a GPU.  A NULL workspace makes the launch
+    branch return PINN_ERR_NULL (-4) before anything touches a device: -4 = "would have launched", 0 = "caller decides",
+    2 = "the ticket never came"."""
+    import ctypes
+    from pde_amd._native import load_library
+    lib = load_library()
+    rng = np.random.default_rng(11)
+    host = np.zeros(16, dtype=np.float32)
+    vals = (ctypes.c_float * 12)()
+    hp = host.ctypes.data_as(ctypes.c_void_p)
+
+    def call(ticket, f_prev, lr, tol_x, tol_g, allow, spins=10):
+        return lib.pinn_lbfgs_poll_advance(hp, ticket, spins, f_prev, lr, tol_x, tol_g, allow, None, 100, 5, None, None, None,
+                                           None, None, None, vals)
+
+    host.view(np.int32)[12] = 7
+    assert call(8, 1.0, 1.0, 1e-9, 1e-7, 1) == 2                      # wrong ticket: gives up after max_spins
+    n_launch = n_back = 0
+    for trial in range(4000):
+        lr = float(rng.choice([1.0, 0.5]))
+        tol_x, tol_g = float(rng.choice([1e-9, 2.2e-16, 1e-3])), float(rng.choice([1e-7, 1e-5, 1e-2]))
+        f_prev = float(np.float32(rng.uniform(0.1, 2.0)))
+        gtd = np.float32(-rng.uniform(0.0, 1.0) * (10.0 ** rng.integers(-12, 1)))
+        if trial % 17 == 0:
+            gtd = np.float32(abs(gtd))                                # not a descent direction
+        dmax = np.float32(10.0 ** rng.uniform(-12, 0))
+        # around the Armijo line and the curvature bound, on both sides
+        fs = np.float32(f_prev + 1e-4 * lr * float(gtd) + rng.normal() * 10.0 ** rng.integers(-9, -1))
+        gtds = np.float32(-0.9 * float(gtd) * rng.uniform(-1.3, 1.3))
+        gmaxs = np.float32(10.0 ** rng.uniform(-8, 0))
+        if trial % 29 == 0:
+            fs = np.float32(np.nan)
+        host[:12] = [gtd, 1.0, dmax, 0.5, 3.0, 1.0, 1.0, 0.0, fs, gtds, gmaxs, 2.0]
+        host.view(np.int32)[12] = trial
+        allow = trial % 13 != 0
+        rc = call(trial, f_prev, lr, tol_x, tol_g, 1 if allow else 0)
+        assert list(vals) == host[:12].tolist() or np.isnan(fs)
+        g, d_, f_, gt, gm = float(gtd), float(dmax), float(fs), float(gtds), float(gmaxs)
+        fast = (allow and not g > -tol_x and not f_ > f_prev + 1e-4 * lr * g and abs(gt) <= -0.9 * g
+                and not gm <= tol_g and not d_ * abs(lr) <= tol_x and not abs(f_ - f_prev) < tol_x)
+        assert rc == (-4 if fast else 0), (trial, rc, fast)
+        n_launch += fast
+        n_back += not fast
+    assert n_launch > 300 and n_back > 300
