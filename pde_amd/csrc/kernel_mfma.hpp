@@ -57,7 +57,13 @@ constexpr int STAGE_TILE = 16 * STAGE_ROW;
 
 template <int W> struct WidthCfg {
     static constexpr int REM = W % 16;
-    static constexpr bool TAIL = (REM != 0 && REM <= 4 && W > 16);
+    // tail neurons on the VALU pay from three MFMA tiles on (width 50 = 48 + 2: padding to 64 costs the 7kdv net +33 %
+    // and spills); width 20 as 16 + 4 was 25-40 % SLOWER than padded to two tiles (r03: 10 000 points 133 -> 80 us,
+    // 1M points 3.51 -> 2.64 ms): below 48 the tail rows / columns / replicated tanh outweigh the padded MFMAs
+#ifndef PINN_TAIL_MIN_W
+#define PINN_TAIL_MIN_W 32
+#endif
+    static constexpr bool TAIL = (REM != 0 && REM <= 4 && W > PINN_TAIL_MIN_W);
     static constexpr int NT = TAIL ? W / 16 : (W + 15) / 16;  // MFMA neuron tiles
     static constexpr int R = TAIL ? REM : 0;                   // tail neurons on the VALU
     static constexpr int RR = R > 0 ? R : 1;                   // array extent
@@ -1328,6 +1334,8 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
 #define PINN_MFMA_WIDTHS(X) X(100)
 #elif defined(PINN_DEV_CH_ONLY)
 #define PINN_MFMA_WIDTHS(X) X(50) X(64)
+#elif defined(PINN_DEV_BURGERS_ONLY)
+#define PINN_MFMA_WIDTHS(X) X(20) X(50)
 #else
 #define PINN_MFMA_WIDTHS(X) X(20) X(50) X(64) X(100)
 #endif
@@ -1423,6 +1431,8 @@ int launch_mfma_eq(float *stash, int eq, const KDesc &kd, const CallArgs &a, int
     case EQ_GNSS:    return launch_mfma_w<EQ_GNSS, MODE>(stash, kd, a, grid, st);
 #elif defined(PINN_DEV_CH_ONLY)
     case EQ_CH:      return launch_mfma_w<EQ_CH, MODE>(stash, kd, a, grid, st);
+#elif defined(PINN_DEV_BURGERS_ONLY)
+    case EQ_BURGERS: return launch_mfma_w<EQ_BURGERS, MODE>(stash, kd, a, grid, st);
 #else
 #ifndef PINN_DEV_KDV7_ONLY
     case EQ_NONE:    return launch_mfma_w<EQ_NONE, MODE>(stash, kd, a, grid, st);

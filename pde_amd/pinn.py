@@ -76,9 +76,10 @@ class PhysicsInformedNN:
     default_device = None            # None -> current CUDA device
     kernel = KERNEL_AUTO
     use_hip_graph = False            # train(): replay the Adam phase / the L-BFGS closure from a captured HIP graph
-    # eager backward(): the collocation kernel on a second stream beside the data-term chain.  None = automatic: on,
-    # on a GPU (round 3, at 20 000 points: Burgers +11 %, 5kdv / 7kdv +7 % closures/s, GNSS width 100 +30 %; in round 2 the
-    # host work of two streams cost the width-50 nets 20 % - their eager closures were host-bound then)
+    # eager backward(): the collocation kernel on a second stream beside the data-term chain.  None = automatic: when
+    # that kernel is long enough to pay for the host work of two streams, N_f x P >= 1e8 (round 3, eager Adam steps/s
+    # with / without: 7kdv at 20 000 points 3 877 / 3 194, GNSS-100 1 841 / 1 365, but Burgers 4x50 at 10 000 points
+    # 4 940 / 5 202 and Burgers 8x20 4 733 / 7 018: closures that short are host-bound)
     overlap_streams = None
     closure_impl = "direct"          # backward(): "direct" (no autograd graph, see _loss_terms_direct) or "autograd"
     hip_graph_fallback = False       # a failed capture raises; True: report it and continue with the eager loop
@@ -663,7 +664,7 @@ class PhysicsInformedNN:
         returns the 0-dim loss with `.grad` accumulated on dnn.parameters()."""
         ov = self.overlap_streams
         if ov is None:
-            ov = True
+            ov = self.xf.shape[0] * self.engine_f.P >= 1e8
         terms = self._loss_terms(overlap=ov)
         self._log_terms(terms)
         self.iter += 1
