@@ -357,7 +357,8 @@ def main():
             "train_hip_graph": graph_info,
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel_ms": 1e3 * k_avg,
+                         "kernel_ms": 1e3 * k_avg, "kernel_ms_min": 1e3 * min(kt), "kernel_ms_max": 1e3 * max(kt),
+                         "kernel_launches_timed": len(kt),
                          "algorithmic_flops_per_point": flops_pp,
                          "note": "FP32 compute roofline (vector == f32-input MFMA peak); "
                                  "algorithmic HBM traffic is 8 B/point (x, t in); `traffic` = HBM bytes per launch "
