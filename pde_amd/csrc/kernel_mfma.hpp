@@ -378,10 +378,27 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
     static_assert(!GROUPED || R * ZTL_J * 16 <= STAGE_TILE, "tail set does not fit the staging tile");
     float *const atl = GROUPED ? stage : lds + L.atl + wv * (R * ZTL_J * 16);
 
-    // Tiles are dealt to workgroups first and to the waves of a workgroup second (tile = block + grid * (wave +
-    // waves * k)): a launch with fewer tiles than wave slots (the scripts' N_f = 10 000 .. 16 000) then spreads
-    // over all CUs and over the four SIMDs of each CU before any SIMD has to interleave two tiles.
-    for (long long tile = blockIdx.x + (long long)gridDim.x * wv; tile < ntiles; tile += nwaves) {
+    // Tiles are dealt to workgroups first and to the waves of a workgroup second (tile = block + grid * wave):
+    // a launch with fewer tiles than wave slots (the scripts' N_f = 10 000 .. 16 000) then spreads over all CUs
+    // and over the four SIMDs of each CU before any SIMD has to interleave two tiles.  That is the FIRST tile of
+    // every wave; a launch with more tiles than waves hands the rest out first come, first served from a counter
+    // in the launch's workspace: dealt statically (tile += nwaves) the CUs drift apart by several tiles over the
+    // 30 rounds of a 1M-point launch and the launch lasts as long as the slowest one (7kdv: 6.27 -> 5.85 ms).
+    // The counters start at zero and the last wave to finish puts them back (no clearing launch, replays from a
+    // HIP graph); launches that share a workspace must not overlap, which they must not anyway (stash, slab).
+    const bool dyn = a.tile_ctr != nullptr && ntiles > nwaves;
+    long long tile = blockIdx.x + (long long)gridDim.x * wv;
+    for (bool first = true;; first = false) {
+        if (!first) {
+            if (dyn) {
+                int t = 0;
+                if (lane0 == 0) t = atomicAdd(&a.tile_ctr[0], 1);
+                tile = nwaves + __builtin_amdgcn_readfirstlane(t);
+            } else {
+                tile += nwaves;
+            }
+        }
+        if (tile >= ntiles) break;
         PINN_REFRESH();
         // (point index and validity are re-derived where they are needed again, not kept live)
         const long long pc = (tile * 16 + p < a.n) ? tile * 16 + p : a.n - 1;
@@ -1282,6 +1299,14 @@ __global__ __launch_bounds__(WidthCfg<W>::block(EqTraits<EQ>::K + 1 + EqTraits<E
         }
     }
 
+    if (dyn && lane0 == 0) {
+        // every wave's last request has returned before it counts itself out: after the last one nothing touches
+        // the counters any more
+        if (atomicAdd(&a.tile_ctr[1], 1) == (int)nwaves - 1) {
+            atomicExch(&a.tile_ctr[0], 0);
+            atomicExch(&a.tile_ctr[1], 0);
+        }
+    }
     PINN_REFRESH();
     if (MODE != MODE_FWD) {
         if (MODE == MODE_LOSS) {

@@ -33,6 +33,7 @@ struct CallArgs {
     float *f_out;        // MODE_FWD: [n][nf] or null
     float *derivs_out;   // MODE_FWD: [n][nout][J] or null
     float *slab;         // MODE_VJP/LOSS: per-workgroup partials [grid][P+2]
+    int *tile_ctr;       // MFMA kernels: [2] zeroed counters (tiles handed out, waves finished) of the launch's workspace, or null
 };
 
 __device__ __forceinline__ float wave_sum(float v)

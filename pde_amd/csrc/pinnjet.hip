@@ -28,6 +28,7 @@ struct pinn_handle {
     size_t jets_bytes = 0;
     float *slab = nullptr;       // per-workgroup partial [grid][P+2]
     size_t slab_bytes = 0;
+    int *tile_ctr = nullptr;     // MFMA kernels: the two counters tiles are handed out from (zero between launches)
     int mfma_grid = 0;           // persistent grid of the MFMA kernels (<= n_cu)
     int spare_cus = 32;          // CUs a small launch leaves free for launches on other streams: one per shader
                                  // engine of every XCD (with 8 or 16, a 31-workgroup fill still queued behind the launch)
@@ -266,11 +267,14 @@ int run(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, float *
     if (fixed) {
         // size the (persistent) grid to the fixed region; every kernel strides its tiles over whatever grid it gets
         const size_t per_wg = nd.jets_per_wg + nd.slab_per_wg;
-        const long long fit = per_wg ? (long long)((fixed->bytes - 256) / per_wg) : grid;
+        // (the region's last 256 bytes hold the tile counters: zero when the code object is loaded, put back to
+        // zero by every launch that uses them)
+        const long long fit = per_wg ? (long long)((fixed->bytes - 512) / per_wg) : grid;
         if (fit < 1) return PINN_ERR_TOO_LARGE;
         if (fit < grid) grid = (int)fit;
         jets = (float *)fixed->base;
         slab = (float *)(fixed->base + align256(nd.jets_per_wg * grid));
+        a.tile_ctr = (int *)(fixed->base + fixed->bytes - 256);
     } else {
         rc = ensure(&h->jets, &h->jets_bytes, nd.jets_per_wg * grid);
         if (rc) return rc;
@@ -278,6 +282,7 @@ int run(pinn_handle *h, int eq, int mode, CallArgs a, float *grad_accum, float *
         if (rc) return rc;
         jets = h->jets;
         slab = h->slab;
+        a.tile_ctr = h->tile_ctr;
     }
     if (mode != MODE_FWD) a.slab = slab;
     if (nd.zero_slab) {
@@ -379,6 +384,13 @@ int pinn_create(const pinn_desc *desc, pinn_handle **out)
 #endif
     // set-up work of the no-allocation entry point: this device's address of the static scratch array
     { const int rc = static_scratch_lookup(h->device); if (rc) { delete h; return rc; } }
+    // the counters the MFMA kernels hand their tiles out from: zeroed once, here; every launch leaves them at zero
+    if (kernel == PINN_KERNEL_MFMA) {
+        if (hipMalloc((void **)&h->tile_ctr, 256) != hipSuccess) { (void)hipGetLastError(); delete h; return PINN_ERR_ALLOC; }
+        if (hipMemset(h->tile_ctr, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError(); (void)hipFree(h->tile_ctr); delete h; return PINN_ERR_HIP;
+        }
+    }
     *out = h;
     return PINN_OK;
 }
@@ -388,6 +400,7 @@ int pinn_destroy(pinn_handle *h)
     if (!h) return PINN_OK;
     if (h->jets) (void)hipFree(h->jets);
     if (h->slab) (void)hipFree(h->slab);
+    if (h->tile_ctr) (void)hipFree(h->tile_ctr);
     delete h;
     return PINN_OK;
 }
