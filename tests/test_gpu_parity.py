@@ -238,6 +238,32 @@ def test_ragged_sizes_against_oracle(name, kname, kernel):
         assert rel(grad.cpu().numpy(), gref) < 1e-5, n
 
 
+@pytest.mark.parametrize("name,n", [("kdv5_xavier", 70_001), ("ch_w64_xavier", 40_000), ("nls_w100_xavier", 33_333)])
+def test_tiles_handed_out_from_the_counter_cover_every_point_once(name, n):
+    """Launches with more tiles than wave slots (2 048 at eight waves per workgroup) deal only each wave's first tile
+    and hand the rest out from a counter in the handle's workspace, which the last wave to finish puts back to zero:
+    three launches in a row (ragged last tile, the second on fewer points) each against the fp64 oracle - a tile
+    skipped, taken twice, or a counter left dirty would show at the 1e-5 level at once."""
+    path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        pytest.skip("no golden " + name)
+    g = np.load(path)
+    eng = engine_for(g, KERNEL_MFMA)
+    o = Oracle(str(g["eq"]), g["layers"].tolist(), g["lb"], g["ub"])
+    rng = np.random.default_rng(5)
+    th64 = g["theta"].astype(np.float64)
+    X = (g["lb"] + (g["ub"] - g["lb"]) * rng.random((n, 2))).astype(np.float32)
+    x, t, theta = cu(X[:, 0]), cu(X[:, 1]), cu(g["theta"])
+    for m in (n, n - 4_097, n):
+        ls = torch.zeros(eng.nf, device=dev())
+        grad = torch.zeros(eng.P, device=dev())
+        eng.loss_grad(theta, x[:m], t[:m], 1.0 / m, ls, grad)
+        lref, gref = o.loss_grad(th64, X[:m, 0], X[:m, 1], scale=1.0 / m)
+        torch.cuda.synchronize()
+        assert rel(ls.cpu().numpy(), lref) < 1e-5, m
+        assert rel(grad.cpu().numpy(), gref) < 1e-5, m
+
+
 @pytest.mark.parametrize("eq,width,depth", [
     ("kdv7_3sol", 50, 1), ("kdv7_3sol", 50, 2), ("kdv7_3sol", 50, 6),     # 1 / 2 / 6 tanh layers (bc nets use 5-6)
     ("ch", 64, 1), ("ch", 64, 2), ("ch", 64, 6),
