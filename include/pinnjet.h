@@ -26,8 +26,13 @@
  *  - return value: 0 = ok, negative = error (pinn_error_string()); nothing is
  *    printed and nothing aborts.
  *  - a handle's entry points must not be called concurrently from two host
- *    threads/streams (they share the handle's device workspace); distinct
- *    handles are independent.
+ *    threads/streams (they share the handle's device workspace: the reverse
+ *    sweep's stash, the per-workgroup partial sums and the two counters from
+ *    which a launch hands its tiles out, which every launch leaves at zero);
+ *    distinct handles are independent;
+ *  - which workgroup sums which points is decided while a launch runs (tiles
+ *    are handed out first come, first served): two launches on the same inputs
+ *    agree to float32 summation order, not bit for bit.
  */
 #ifndef PINNJET_H
 #define PINNJET_H
