@@ -8,10 +8,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int WIDE>
-__global__ __launch_bounds__(512, 1) void k(float *stash, long long region_floats, int rounds, float *out)
+__global__ __launch_bounds__(512, 1) void k(float *stash, long long region_floats, long long stride_floats, int rounds, float *out)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float *st = stash + ((long long)blockIdx.x * 8 + wv) * region_floats;
+    float *st = stash + ((long long)blockIdx.x * 8 + wv) * stride_floats;
     float acc = 0.f;
     for (int r = 0; r < rounds; ++r) {
         if (WIDE) {
@@ -27,15 +27,16 @@ __global__ __launch_bounds__(512, 1) void k(float *stash, long long region_float
     if (acc == 123.456f) out[threadIdx.x] = acc;
 }
 
-template <int WIDE> static void run(float *stash, float *out, long long region_bytes, const char *name)
+template <int WIDE> static void run(float *stash, float *out, long long region_bytes, const char *name, long long stride_bytes = 0)
 {
+    if (!stride_bytes) stride_bytes = region_bytes;
     const int rounds = 30;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e30f;
     for (int it = 0; it < 3; ++it) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(k<WIDE>, dim3(256), dim3(512), 0, 0, stash, region_bytes / 4, rounds, out);
+        hipLaunchKernelGGL(k<WIDE>, dim3(256), dim3(512), 0, 0, stash, region_bytes / 4, stride_bytes / 4, rounds, out);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -57,5 +58,9 @@ int main()
     run<1>(stash, out, 64 * 1024, "b128 stores and loads");
     run<0>(stash, out, 64 * 1024, "dword stores and loads");
     run<1>(stash, out, 16 * 1024, "b128 stores and loads");
+    // what the 7kdv kernel touches: 138 KB of each wave's 221 KB (283 MB in all), and a set just inside the cache
+    run<1>(stash, out, 138 * 1024, "b128, 138 KB touched of a 221 KB stride", 221 * 1024);
+    run<1>(stash, out, 110 * 1024, "b128, 110 KB touched of a 221 KB stride", 221 * 1024);
+    run<1>(stash, out, 96 * 1024, "b128,  96 KB touched of a 221 KB stride", 221 * 1024);
     return 0;
 }
